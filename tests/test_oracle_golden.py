@@ -1,0 +1,97 @@
+"""Pins the CPU oracle (oracle/crw_oracle.py) to outputs of the reference itself (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import crw_oracle as orc
+from conftest import load_golden
+
+WALK_CASES = ["walk_cfg1_B2T8N7", "walk_odd_B1T4N5", "walk_onecycle_B3T3N6", "walk_cfg2_B1T16N63",
+              "walk_N70_B2T6", "walk_cfg3_B1T32N63", "walk_noise_B2T8N7_tau0p1"]
+
+
+@pytest.mark.parametrize("name", WALK_CASES)
+def test_walk_matches_reference(name):
+    g = load_golden(name)
+    tau = float(g["tau"])
+    o = orc.crw_from_features(g["emb"], tau, np.float64)
+    np.testing.assert_allclose(o["A"], g["A"], rtol=2e-5, atol=2e-4)  # golden is fp32 (|A| <= 1/tau)
+    np.testing.assert_allclose(o["loss"], g["loss"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(o["At"], g["At"], rtol=1e-4, atol=2e-6)
+    scale = np.abs(g["demb"]).max()
+    np.testing.assert_allclose(o["demb"], g["demb"], rtol=2e-3, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize("name", ["walk_cfg1_B2T8N7", "walk_odd_B1T4N5", "walk_noise_B2T8N7_tau0p1"])
+def test_prefix_form_equals_reference_form(name):
+    g = load_golden(name)
+    A = orc.affinity(orc.l2_normalize(g["emb"]), float(g["tau"]))
+    l1, At1 = orc.walk_reference_form(A)
+    l2, At2 = orc.walk_prefix_form(A)
+    np.testing.assert_allclose(l1, l2, rtol=1e-13)
+    np.testing.assert_allclose(At1, At2, rtol=1e-10, atol=1e-14)
+
+
+def test_fp32_oracle_close_to_reference():
+    g = load_golden("walk_cfg3_B1T32N63")
+    o = orc.crw_from_features(g["emb"], float(g["tau"]), np.float32)
+    assert abs(float(o["loss"]) - float(g["loss"])) < 1e-5
+    np.testing.assert_allclose(o["At"], g["At"], rtol=1e-3, atol=2e-5)
+
+
+def test_no_cycle_when_T_lt_3():
+    g = load_golden("walk_T2_nocycle")
+    o = orc.crw_from_features(g["emb"], float(g["tau"]))
+    assert float(o["loss"]) == 0.0 == float(g["loss"])
+    np.testing.assert_allclose(o["A"], g["A"], rtol=2e-5, atol=1e-4)
+
+
+def test_torch_walk_equals_numpy_walk():
+    g = load_golden("walk_cfg1_B2T8N7")
+    emb = torch.tensor(g["emb"], dtype=torch.float64, requires_grad=True)
+    loss, A = orc.walk_loss_torch(emb, float(g["tau"]))
+    loss.backward()
+    o = orc.crw_from_features(g["emb"], float(g["tau"]))
+    np.testing.assert_allclose(loss.item(), o["loss"], rtol=1e-12)
+    np.testing.assert_allclose(emb.grad.numpy(), o["demb"], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,wname", [("cnn_cfg1_B2T8N7", "cnn_weights_seed11"),
+                                        ("cnn_posembed_B1T4N3", "cnn_weights_posembed_seed21")])
+def test_cnn_path_matches_reference(name, wname):
+    g, w = load_golden(name), load_golden(wname)
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+    loss, A, emb = orc.crw_forward_torch(torch.tensor(g["seq"]), sd, float(g["tau"]), bool(g["pos_embed"]))
+    np.testing.assert_allclose(emb.detach().numpy(), g["emb"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(A.detach().numpy(), g["A"], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    loss.backward()
+    for k in w:
+        ref = g["grad." + k]
+        np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=5e-3, atol=5e-4 * np.abs(ref).max())
+
+
+LP_CASES = ["labelprop_trunc_T14N10", "labelprop_full_T40N48", "labelprop_last_T20N24", "labelprop_mc1_T100N12"]
+
+
+@pytest.mark.parametrize("name", LP_CASES)
+def test_labelprop_matches_reference(name):
+    g = load_golden(name)
+    emb = g["emb"][::-1].copy() if bool(g["use_last"]) else g["emb"]
+    T, N, C = emb.shape
+    seed = orc.seed_labels(g["seg_ref"], N)
+    pred = orc.labelprop(emb, seed, int(g["nclasses"]), int(g["cxt_size"]), int(g["radius"]),
+                         float(g["temp"]), int(g["knn"]))
+    assert pred.shape == g["pred"].shape
+    assert np.array_equal(pred, g["pred"]), f"{(pred != g['pred']).sum()} labels differ"
+    np.testing.assert_allclose(orc.xent_metric(emb), g["xent"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["dataset_64x256", "dataset_50x200_ow"])
+def test_dataset_unfold_matches_reference(name):
+    g = load_golden(name)
+    dim, ov, L = tuple(int(x) for x in g["dim"]), tuple(int(x) for x in g["overlap"]), int(g["length"])
+    nh, nw, pxh, pxw = orc.dataset_geometry(g["rg"].shape[0], g["rg"].shape[1], L, dim, ov)
+    assert nw == int(g["n_items"])
+    for i, idx in enumerate(g["picks"]):
+        assert np.array_equal(orc.unfold_item(g["rg"], int(idx), L, dim, ov), g["items"][i])
