@@ -1,0 +1,116 @@
+/*
+ * crw_hip.h -- C ABI of libcrw_hip.so: the MI355X (gfx950) implementation of the
+ * contrastive-random-walk hot path of jdalcorso/radar-sounder-crw.
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; its hot path is the sequence
+ * of ATen calls listed below.  Each entry point replaces one such group of calls
+ * (file:line under the reference repo):
+ *
+ *   crw_affinity_fwd ........ F.normalize + einsum('bctn,bctm->btnm')/tau      src/model.py:22-26
+ *   crw_walk_fwd ............ palindrome cat + (T-2)^2 x {softmax,bmm} +
+ *                             (T-2) x cross_entropy + loss/N                  src/model.py:31-46
+ *   crw_walk_bwd ............ autograd backward of the above                  (loss.backward(), scripts/train.py:71)
+ *   crw_affinity_bwd ........ autograd backward of normalize+einsum           (same)
+ *   crw_labelprop_topk ...... einsum + mask + /temp + truncation + topk +
+ *                             softmax                                         src/imported/maskedatt.py:151-175
+ *   crw_labelprop_gather .... weighted label sum + argmax, frame by frame     src/imported/labelprop.py:106-114, src/utils.py:152-160
+ *   crw_xent_metric ......... "horizontality" metric                          src/utils.py:117-125
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *   - tensors are dense row-major fp32 with the shapes given per function;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); nothing synchronises;
+ *   - no allocation inside: workspaces are sized with the crw_*_bytes() queries and passed in;
+ *   - return value: CRW_OK or an error code; nothing is thrown across the ABI; the library is
+ *     stateless and thread-safe (one caller per stream).
+ */
+#ifndef CRW_HIP_H
+#define CRW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRW_OK 0
+#define CRW_EINVAL 1     /* bad shape / null pointer / unsupported size            */
+#define CRW_EWORKSPACE 2 /* workspace too small                                     */
+#define CRW_EHIP 3       /* a HIP launch failed (see crw_last_hip_error)            */
+
+/* arithmetic used inside the transition-matrix chain */
+#define CRW_CHAIN_F32 0  /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32), parity path   */
+#define CRW_CHAIN_BF16 1 /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
+
+typedef void *crw_stream_t;
+
+/* library / build info ------------------------------------------------------------------- */
+int crw_abi_version(void);          /* bumps when a signature changes                       */
+const char *crw_build_arch(void);   /* "gfx950"                                             */
+int crw_last_hip_error(void);       /* last hipError_t seen by this thread (0 = none)       */
+
+/* geometry ------------------------------------------------------------------------------- */
+/* node count padded to the tile size of the chain GEMM (all internal NxN matrices are stored
+ * [Np][Np] with zero padding). */
+int crw_padded_nodes(int N);
+/* bytes of the state buffer written by crw_walk_fwd and consumed by crw_walk_bwd */
+size_t crw_walk_state_bytes(int B, int T, int N);
+/* bytes of the scratch buffer needed by crw_walk_bwd */
+size_t crw_walk_scratch_bytes(int B, int T, int N);
+
+/* training path --------------------------------------------------------------------------- */
+/* emb [B,T,N,C] raw encoder output -> ehat [B,T,N,C] (L2-normalised, eps 1e-12),
+ * norm [B,T,N] (= max(||e||, eps)), A [B,T-1,N,N] = ehat_t ehat_{t+1}^T / tau. */
+int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau,
+                     float *ehat, float *norm, float *A, crw_stream_t stream);
+
+/* A [B,T-1,N,N] -> loss[1] (= sum_k l_k / N, Appendix A.2 of SURVEY.md).
+ * state: crw_walk_state_bytes(B,T,N) bytes, kept by the caller until crw_walk_bwd.
+ * At_out: optional [B,T-2,N,N] copy of every per-cycle transition product (may be NULL).
+ * chain: CRW_CHAIN_F32 | CRW_CHAIN_BF16.   T < 3 -> loss = 0. */
+int crw_walk_fwd(const float *A, int B, int T, int N, int chain,
+                 void *state, size_t state_bytes, float *At_out, float *loss, crw_stream_t stream);
+
+/* gloss[1] (device scalar, dL/dloss) + state -> dA [B,T-1,N,N]. */
+int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain,
+                 void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
+                 float *dA, crw_stream_t stream);
+
+/* dA [B,T-1,N,N], ehat, norm -> demb [B,T,N,C]; dehat_ws is a [B,T,N,C] scratch. */
+int crw_affinity_bwd(const float *dA, const float *ehat, const float *norm, int B, int T, int N, int C,
+                     float tau, float *dehat_ws, float *demb, crw_stream_t stream);
+
+/* inference path -------------------------------------------------------------------------- */
+/* emb [T,N,C] raw -> ehat [T,N,C] (reuses the normalise kernel of crw_affinity_fwd). */
+int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, crw_stream_t stream);
+
+/* For every frame n = first_frame..T-1 (first_frame >= 1; 1 = whole radargram, T-1 = the
+ * reference's one-frame-at-a-time LabelPropVOS_CRW.predict) and query node q: top-`knn` keys among the context frames
+ * (frame 0 + last `cxt_size` frames once n > cxt_size+1, else frames 0..n-1) restricted to the
+ * band |m-q| < radius, logits <key,query>/temp, softmax over the knn.
+ * W [T-first_frame,knn,N] weights, I [same] int32 indices into the (truncated) key list.
+ * Requires 1 <= radius, 1 <= knn <= 64. Slots beyond the number of in-band keys get weight 0
+ * (the reference fills them with masked keys whose softmax weight is exactly 0). */
+int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp,
+                       int knn, int first_frame, float *W, int32_t *I, crw_stream_t stream);
+
+/* seed [N] float class ids of frame 0 (NULL: rows of L for frames < first_frame are already
+ * filled by the caller); W,I from crw_labelprop_topk with the same first_frame;
+ * L [T*N, M] soft labels (frames >= first_frame written), pred [N,T] float class ids
+ * (columns >= first_frame written; column 0 = seed when seed is given). */
+int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn,
+                         int first_frame, float *L, float *pred, crw_stream_t stream);
+
+/* ehat [T,N,C] -> xent [N,T-1]  (channel-shifted within-frame affinity / 0.1, CE vs identity) */
+int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream);
+
+/* building blocks exported for tests and the roofline bench --------------------------------- */
+/* X [batch,n,n] (n multiple of 32, zero padded): C = op(A) * op(B) (+ C if beta), fp32 MFMA. */
+int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
+                 int beta, crw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRW_HIP_H */

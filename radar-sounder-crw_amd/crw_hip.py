@@ -1,0 +1,169 @@
+"""ctypes binding of libcrw_hip.so (C ABI: include/crw_hip.h) for the Python host code.
+
+PyTorch-ROCm is plumbing here: it owns device memory and streams; every product computation of
+the random walk goes through the HIP library.  There is NO fallback: if the library is missing or
+a tensor is not on an MI355X device the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrw_hip.so")
+
+CRW_OK, CRW_EINVAL, CRW_EWORKSPACE, CRW_EHIP = 0, 1, 2, 3
+CHAIN_F32, CHAIN_BF16 = 0, 1
+_ERR = {1: "CRW_EINVAL (bad shape / null pointer / unsupported size)",
+        2: "CRW_EWORKSPACE (workspace too small)", 3: "CRW_EHIP (HIP launch failed)"}
+
+_c_int, _c_f, _c_sz, _p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/crw_hip.h one to one
+SIGNATURES = {
+    "crw_abi_version": (_c_int, []),
+    "crw_build_arch": (ctypes.c_char_p, []),
+    "crw_last_hip_error": (_c_int, []),
+    "crw_padded_nodes": (_c_int, [_c_int]),
+    "crw_walk_state_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_walk_scratch_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_affinity_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p, _p]),
+    "crw_walk_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _p, _p]),
+    "crw_walk_bwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _c_sz, _p, _p]),
+    "crw_affinity_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p]),
+    "crw_normalize": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
+    "crw_labelprop_topk": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _p, _p, _p]),
+    "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
+    "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built: `python -c 'import
+    __graft_entry__ as g; g.build()'` or `make -C radar-sounder-crw_amd/csrc`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built -- the CRW hot path has no CPU/PyTorch fallback; "
+                               "run `make -C radar-sounder-crw_amd/csrc` (hipcc --offload-arch=gfx950)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def _check(status, what):
+    if status != CRW_OK:
+        raise RuntimeError(f"{what} failed: {_ERR.get(status, status)} (hipError {lib().crw_last_hip_error()})")
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on an MI355X device (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous {dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def padded_nodes(N):
+    return lib().crw_padded_nodes(N)
+
+
+# ------------------------------------------------------------------------------ training path
+def affinity_fwd(emb, tau):
+    """emb [B,T,N,C] -> (A [B,T-1,N,N], ehat, norm)."""
+    B, T, N, C = emb.shape
+    ehat = torch.empty_like(emb)
+    norm = torch.empty(B, T, N, device=emb.device, dtype=torch.float32)
+    A = torch.empty(B, T - 1, N, N, device=emb.device, dtype=torch.float32)
+    _check(lib().crw_affinity_fwd(_dev(emb, "emb"), B, T, N, C, float(tau), _dev(ehat, "ehat"), _dev(norm, "norm"),
+                                  _dev(A, "A"), _stream()), "crw_affinity_fwd")
+    return A, ehat, norm
+
+
+def affinity_bwd(dA, ehat, norm, tau):
+    B, T, N, C = ehat.shape
+    ws = torch.empty_like(ehat)
+    demb = torch.empty_like(ehat)
+    _check(lib().crw_affinity_bwd(_dev(dA, "dA"), _dev(ehat, "ehat"), _dev(norm, "norm"), B, T, N, C, float(tau),
+                                  _dev(ws, "ws"), _dev(demb, "demb"), _stream()), "crw_affinity_bwd")
+    return demb
+
+
+def walk_fwd(A, chain=CHAIN_F32, want_At=False):
+    """A [B,T-1,N,N] -> (loss 0-d, state buffer, At [B,T-2,N,N] or None)."""
+    B, Tm1, N, _ = A.shape
+    T = Tm1 + 1
+    nbytes = lib().crw_walk_state_bytes(B, T, N)
+    state = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    loss = torch.empty((), dtype=torch.float32, device=A.device)
+    At = torch.empty(B, max(T - 2, 0), N, N, device=A.device, dtype=torch.float32) if want_At else None
+    _check(lib().crw_walk_fwd(_dev(A, "A"), B, T, N, chain, ctypes.c_void_p(state.data_ptr()), nbytes,
+                              _dev(At, "At") if (want_At and T > 2) else None, _dev(loss, "loss"), _stream()),
+           "crw_walk_fwd")
+    return loss, state, At
+
+
+def walk_bwd(gloss, state, B, T, N, chain=CHAIN_F32):
+    nbytes = lib().crw_walk_scratch_bytes(B, T, N)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=state.device)
+    dA = torch.empty(B, T - 1, N, N, device=state.device, dtype=torch.float32)
+    g = gloss.reshape(1).to(torch.float32).contiguous()
+    _check(lib().crw_walk_bwd(_dev(g, "gloss"), B, T, N, chain, ctypes.c_void_p(state.data_ptr()), state.numel(),
+                              ctypes.c_void_p(scratch.data_ptr()), nbytes, _dev(dA, "dA"), _stream()), "crw_walk_bwd")
+    return dA
+
+
+# ------------------------------------------------------------------------------ inference path
+def normalize(emb):
+    rows, C = emb.numel() // emb.shape[-1], emb.shape[-1]
+    ehat = torch.empty_like(emb)
+    _check(lib().crw_normalize(_dev(emb, "emb"), rows, C, _dev(ehat, "ehat"), None, _stream()), "crw_normalize")
+    return ehat
+
+
+def labelprop_topk(ehat, cxt_size, radius, temp, knn, first_frame=1):
+    T, N, C = ehat.shape
+    W = torch.empty(T - first_frame, knn, N, device=ehat.device, dtype=torch.float32)
+    I = torch.empty(T - first_frame, knn, N, device=ehat.device, dtype=torch.int32)
+    _check(lib().crw_labelprop_topk(_dev(ehat, "ehat"), T, N, C, int(cxt_size), int(radius), float(temp), int(knn),
+                                    int(first_frame), _dev(W, "W"), _dev(I, "I", torch.int32), _stream()),
+           "crw_labelprop_topk")
+    return W, I
+
+
+def labelprop_gather(seed, W, I, T, N, M, first_frame=1, L=None, pred=None):
+    knn = W.shape[1]
+    if L is None:
+        L = torch.empty(T * N, M, device=W.device, dtype=torch.float32)
+    if pred is None:
+        pred = torch.zeros(N, T, device=W.device, dtype=torch.float32)
+    _check(lib().crw_labelprop_gather(_dev(seed, "seed") if seed is not None else None, _dev(W, "W"),
+                                      _dev(I, "I", torch.int32), T, N, M, knn, int(first_frame), _dev(L, "L"),
+                                      _dev(pred, "pred"), _stream()), "crw_labelprop_gather")
+    return L, pred
+
+
+def xent_metric(ehat):
+    T, N, C = ehat.shape
+    out = torch.empty(N, T - 1, device=ehat.device, dtype=torch.float32)
+    _check(lib().crw_xent_metric(_dev(ehat, "ehat"), T, N, C, _dev(out, "xent"), _stream()), "crw_xent_metric")
+    return out
+
+
+def gemm_f32(A, B, C=None, transA=False, transB=False, beta=False):
+    batch, n, _ = A.shape
+    if C is None:
+        C = torch.empty_like(A)
+    _check(lib().crw_gemm_f32(_dev(A, "A"), _dev(B, "B"), _dev(C, "C"), n, batch, int(transA), int(transB), int(beta),
+                              _stream()), "crw_gemm_f32")
+    return C

@@ -1,0 +1,115 @@
+// Shared declarations for the gfx950 kernels of libcrw_hip.so (internal; the public ABI is
+// include/crw_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "crw_hip.h"
+
+namespace crw {
+
+constexpr int WAVE = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+extern thread_local int g_last_hip_error;
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return CRW_EHIP;
+  }
+  return CRW_OK;
+}
+
+#define CRW_TRY(expr)               \
+  do {                              \
+    int _st = (expr);               \
+    if (_st != CRW_OK) return _st;  \
+  } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Padded node count: every internal NxN matrix is [Np][Np], zero padded, so the chain GEMM
+// needs no edge handling.  Tile candidates are 32/64/128 (gemm_f32.hip).
+inline int padded_nodes(int N) {
+  if (N <= 128) return round_up(N, 32);
+  if (N <= 1024) return round_up(N, 64);
+  return round_up(N, 128);
+}
+
+// ---- wave-level reductions (64 lanes) -----------------------------------------------------
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- one product of a grouped, batched, zero-padded square GEMM ---------------------------
+// C[b] (+)= op(A[b]) * op(B[b]) [+ op(A2[b]) * op(B2[b])], all [n][n] row-major with ld = n.
+// op(X) = X^T when the matching flag is set.
+struct GemmProb {
+  const void *A, *B, *A2, *B2;
+  float *C;
+  void *Cb;                  // optional bf16 shadow copy of C (bf16 chain), same layout
+  long sA, sB, sA2, sB2, sC; // batch strides in elements
+  int ta, tb, ta2, tb2;
+  int beta;                  // 1: accumulate into the existing C
+};
+constexpr int MAX_GROUP = 6;
+struct GemmGroup {
+  GemmProb p[MAX_GROUP];
+  int nprob;
+  int n;     // padded size
+  int batch; // grid.y
+};
+
+int launch_gemm_group_f32(const GemmGroup &g, hipStream_t s);
+int launch_gemm_group_bf16(const GemmGroup &g, hipStream_t s);
+
+// general (bounds-checked) strided GEMM used by the affinity build and its backward:
+// C[b][m][n] = alpha_div ? acc / alpha : acc * alpha, acc = sum_k A(m,k) B(k,n) (+ second pair)
+struct EdgeOperand {
+  const float *p;
+  long sb;     // batch stride
+  long rs, cs; // strides of the logical (row, col) of the operand as used in the product
+};
+struct EdgeGemm {
+  EdgeOperand A, B, A2, B2; // A2.p == nullptr -> single product
+  float *C;
+  long sCb, ldc;
+  int M, N, K, K2;
+  int batch_inner;          // batch index b = blockIdx.z ; (outer, inner) = (b / inner, b % inner)
+  long sA_outer, sB_outer, sA2_outer, sB2_outer, sC_outer;
+  // per-inner-index enable masks: product 1 is skipped when inner == skip1_inner, product 2 when
+  // inner == skip2_inner (used for the first/last frame in the affinity backward)
+  int skip1_inner, skip2_inner;
+  float scale;
+  int divide;               // 1: C = acc / scale, 0: C = acc * scale
+};
+int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s);
+
+// softmax.hip --------------------------------------------------------------------------------
+int launch_softmax_fwd(const float *A, int nmat, int N, int Np, float *F, float *Gt, void *Fb, void *Gtb,
+                       float *stats /* 4*nmat*Np */, hipStream_t s);
+int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const float *dGt, int nmat, int N,
+                       int Np, float *stats /* 2*nmat*Np */, float *dA, hipStream_t s);
+int launch_identity(float *R, void *Rb, int batch, int Np, int N, hipStream_t s);
+int launch_copy_f32(float *dst, const float *src, long dst_bs, long src_bs, long n_per_batch, int batch,
+                    hipStream_t s);
+int launch_loss_rows(const float *At, int nmat, int N, int Np, float *lse, float *terms, hipStream_t s);
+int launch_loss_reduce(const float *terms, long n, float scale, float *loss, hipStream_t s);
+int launch_dAt(const float *At, const float *lse, const float *gloss, float coef, int nmat, int N, int Np,
+               float *dAt, void *dAtb, hipStream_t s);
+int launch_unpad_At(const float *At, int K, int B, int N, int Np, float *out, hipStream_t s);
+
+}  // namespace crw

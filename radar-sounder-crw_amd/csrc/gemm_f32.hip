@@ -1,0 +1,280 @@
+// fp32 matrix-core GEMMs for the random-walk chain (exact fp32: v_mfma_f32_16x16x4_f32 is a
+// k-ordered fmaf chain, so results are reproducible and within fp32 rounding of the reference's
+// CPU sgemm).
+//
+//  * gemm_pad_f32_kernel  -- grouped + batched product of zero-padded square matrices
+//                            [n][n], n a multiple of the tile.  No edge handling, 16-byte
+//                            global loads, LDS-staged k-major tiles, register prefetch of the
+//                            next k-tile.  One launch carries up to MAX_GROUP independent
+//                            products (the three products of one walk step / the four of one
+//                            backward step), blockIdx.z selects the product.
+//  * edge_gemm_kernel     -- bounds-checked, arbitrarily strided product used for the affinity
+//                            build (K = C = 128) and its backward.
+//
+// Fragment maps (gfx950, 16x16x4 f32): A lane l -> A[row l&15][k l>>4], B lane l -> B[k l>>4][col l&15],
+// C/D reg r of lane l -> C[row (l>>4)*4 + r][col l&15].
+#include "crw_common.h"
+
+namespace crw {
+
+thread_local int g_last_hip_error = 0;
+
+namespace {
+
+constexpr int BK = 16;
+
+// Stage an R x BK operand tile.  Logical element (r, k) of op(X):
+//   kcontig : X[(r0 + r) * n + k0 + k]      (rows of X run along k)
+//   !kcontig: X[(k0 + k) * n + r0 + r]      (rows of X run along r)
+template <int R>
+struct Stager {
+  static constexpr int NV4 = R * BK / 4;                 // float4 per tile
+  static constexpr int PER = (NV4 + 255) / 256;          // float4 per thread
+  float4 v[PER];
+
+  __device__ inline void load(const float *__restrict__ X, int n, int r0, int k0, bool kcontig, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int e = tid + i * 256;
+      if (NV4 % 256 == 0 || e < NV4) {
+        if (kcontig) {
+          int r = e >> 2, kq = e & 3;
+          v[i] = *reinterpret_cast<const float4 *>(X + (long)(r0 + r) * n + k0 + 4 * kq);
+        } else {
+          int k = e / (R / 4), rq = e % (R / 4);
+          v[i] = *reinterpret_cast<const float4 *>(X + (long)(k0 + k) * n + r0 + 4 * rq);
+        }
+      }
+    }
+  }
+  template <int LD>
+  __device__ inline void store(float *S, bool kcontig, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int e = tid + i * 256;
+      if (NV4 % 256 == 0 || e < NV4) {
+        if (kcontig) {
+          int r = e >> 2, kq = e & 3;
+          S[(4 * kq + 0) * LD + r] = v[i].x;
+          S[(4 * kq + 1) * LD + r] = v[i].y;
+          S[(4 * kq + 2) * LD + r] = v[i].z;
+          S[(4 * kq + 3) * LD + r] = v[i].w;
+        } else {
+          int k = e / (R / 4), rq = e % (R / 4);
+          *reinterpret_cast<float4 *>(S + k * LD + 4 * rq) = v[i];
+        }
+      }
+    }
+  }
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_pad_f32_kernel(GemmGroup g) {
+  constexpr int LDA = BM + 16, LDB = BN + 16;  // (LD mod 32) == 16: the two k-rows a 32-lane group reads hit disjoint banks
+  constexpr int TM = BM / 2 / 16, TN = BN / 2 / 16;
+  __shared__ __attribute__((aligned(16))) float lds[BK * LDA + BK * LDB];
+  float *As = lds, *Bs = lds + BK * LDA;
+
+  const GemmProb &p = g.p[blockIdx.z];
+  const int n = g.n;
+  const int tiles_n = n / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const long b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+
+  const int nk = n / BK;
+  const int nprod = p.A2 ? 2 : 1;
+  const int nt = nk * nprod;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Stager<BM> sa;
+  Stager<BN> sb;
+  auto issue = [&](int t) {
+    const bool second = t >= nk;
+    const int k0 = (second ? t - nk : t) * BK;
+    const float *A = second ? (const float *)p.A2 + b * p.sA2 : (const float *)p.A + b * p.sA;
+    const float *Bp = second ? (const float *)p.B2 + b * p.sB2 : (const float *)p.B + b * p.sB;
+    const bool ta = second ? p.ta2 : p.ta, tb = second ? p.tb2 : p.tb;
+    sa.load(A, n, m0, k0, !ta, tid);   // op(A)(m,k): k-contiguous unless transposed
+    sb.load(Bp, n, n0, k0, tb, tid);   // op(B)(k,c): k-contiguous only when transposed
+  };
+  auto commit = [&](int t) {
+    const bool second = t >= nk;
+    const bool ta = second ? p.ta2 : p.ta, tb = second ? p.tb2 : p.tb;
+    sa.template store<LDA>(As, !ta, tid);
+    sb.template store<LDB>(Bs, tb, tid);
+  };
+
+  issue(0);
+  for (int t = 0; t < nt; ++t) {
+    commit(t);
+    __syncthreads();
+    if (t + 1 < nt) issue(t + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[TM], bv[TN];
+      const int kr = kk + (lane >> 4), c = lane & 15;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + wm + i * 16 + c];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[kr * LDB + wn + j * 16 + c];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float *C = p.C + b * p.sC;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
+        float v = acc[i][j][r];
+        float *dst = C + (long)row * n + col;
+        if (p.beta) v += *dst;
+        *dst = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bounds-checked strided GEMM, 64x64 tile, 4 waves of 32x32.
+constexpr int EB = 64, ELD = 65;
+
+__device__ inline void edge_stage(const float *__restrict__ base, long rs, long cs, bool a_side, int R, int K,
+                                  int r0, int k0, float *S, int tid) {
+  // a_side: logical (row=r, col=k) ; b side: logical (row=k, col=r)
+  const long sr = a_side ? rs : cs, sk = a_side ? cs : rs;
+  const bool kfast = (sk == 1);
+#pragma unroll
+  for (int i = 0; i < EB * BK / 256; ++i) {
+    int e = tid + i * 256;
+    int k, r;
+    if (kfast) { k = e % BK; r = e / BK; } else { r = e % EB; k = e / EB; }
+    float v = 0.f;
+    if (r0 + r < R && k0 + k < K) v = base[(long)(r0 + r) * sr + (long)(k0 + k) * sk];
+    S[k * ELD + r] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_gemm_kernel(EdgeGemm g) {
+  __shared__ float As[BK * ELD], Bs[BK * ELD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * EB, n0 = blockIdx.x * EB;
+  const int outer = blockIdx.z / g.batch_inner, inner = blockIdx.z % g.batch_inner;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int prod = 0; prod < 2; ++prod) {
+    const EdgeOperand &oa = prod ? g.A2 : g.A;
+    const EdgeOperand &ob = prod ? g.B2 : g.B;
+    if (oa.p == nullptr) continue;
+    if (inner == (prod ? g.skip2_inner : g.skip1_inner)) continue;
+    const int K = prod ? g.K2 : g.K;
+    const float *A = oa.p + (long)outer * (prod ? g.sA2_outer : g.sA_outer) + (long)inner * oa.sb;
+    const float *Bp = ob.p + (long)outer * (prod ? g.sB2_outer : g.sB_outer) + (long)inner * ob.sb;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+      edge_stage(A, oa.rs, oa.cs, true, g.M, K, m0, k0, As, tid);
+      edge_stage(Bp, ob.rs, ob.cs, false, g.N, K, n0, k0, Bs, tid);
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 4) {
+        const int kr = kk + (lane >> 4), c = lane & 15;
+        float a[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = As[kr * ELD + wm + i * 16 + c];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = Bs[kr * ELD + wn + j * 16 + c];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  float *C = g.C + (long)outer * g.sC_outer + (long)inner * g.sCb;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][r];
+          C[(long)row * g.ldc + col] = g.divide ? v / g.scale : v * g.scale;
+        }
+      }
+    }
+}
+
+// largest tile (128 / 64 / 32) that divides n and still yields a well-filled grid
+int pick_tile(int n, long batch_times_prob) {
+  const int cand[3] = {128, 64, 32};
+  for (int i = 0; i < 3; ++i) {
+    int t = cand[i];
+    if (n % t) continue;
+    long blocks = (long)(n / t) * (n / t) * batch_times_prob;
+    if (blocks >= 512 || t == 32) return t;
+  }
+  return 32;
+}
+
+}  // namespace
+
+int launch_gemm_group_f32(const GemmGroup &g, hipStream_t s) {
+  if (g.nprob < 1 || g.nprob > MAX_GROUP || g.n <= 0 || g.n % 32 || g.batch < 1) return CRW_EINVAL;
+  const int tile = pick_tile(g.n, (long)g.batch * g.nprob);
+  dim3 grid((g.n / tile) * (g.n / tile), g.batch, g.nprob);
+  if (tile == 128)
+    hipLaunchKernelGGL((gemm_pad_f32_kernel<128, 128>), grid, dim3(256), 0, s, g);
+  else if (tile == 64)
+    hipLaunchKernelGGL((gemm_pad_f32_kernel<64, 64>), grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_pad_f32_kernel<32, 32>), grid, dim3(256), 0, s, g);
+  return check_launch();
+}
+
+int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s) {
+  if (g.M < 1 || g.N < 1 || batch < 1) return CRW_EINVAL;
+  dim3 grid((g.N + EB - 1) / EB, (g.M + EB - 1) / EB, batch);
+  hipLaunchKernelGGL(edge_gemm_kernel, grid, dim3(256), 0, s, g);
+  return check_launch();
+}
+
+}  // namespace crw
+
+extern "C" int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
+                            int beta, crw_stream_t stream) {
+  if (!A || !B || !C) return CRW_EINVAL;
+  crw::GemmGroup g{};
+  g.nprob = 1;
+  g.n = n;
+  g.batch = batch;
+  crw::GemmProb &p = g.p[0];
+  p.A = A; p.B = B; p.C = C;
+  p.sA = p.sB = p.sC = (long)n * n;
+  p.ta = transA; p.tb = transB; p.beta = beta;
+  return crw::launch_gemm_group_f32(g, (hipStream_t)stream);
+}

@@ -1,0 +1,220 @@
+// Inference path: k-NN label propagation along the radargram (src/utils.py:134-161,
+// src/imported/labelprop.py:67-115, src/imported/maskedatt.py:151-175) and the
+// "horizontality" metric (src/utils.py:117-125).
+//
+// Restructured for the GPU: the reference recomputes, for every frame n, the affinity of frame n
+// against the whole growing context and only then gathers labels.  Features never change, so
+//   (1) crw_labelprop_topk computes the top-k weights/indices of ALL frames in one launch
+//       (one workgroup per (query node, frame); only in-band keys |m-q| < radius are scored --
+//       out-of-band keys carry logit -1e10/temp whose softmax weight is exactly 0 in fp32);
+//   (2) crw_labelprop_gather is the only sequential part: a single workgroup walks the frames and
+//       does the weighted label sums + argmax.
+// Index quirk kept on purpose: indices address the truncated key list
+// [frame 0, last cxt frames] but are applied to the untruncated label list.
+#include "crw_common.h"
+
+namespace crw {
+namespace {
+
+constexpr int MAX_KNN = 64;
+
+__global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__restrict__ ehat, int T, int N, int C,
+                                                             int cxt, int radius, float temp, int knn,
+                                                             int first_frame, float *__restrict__ W,
+                                                             int32_t *__restrict__ I) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int q = blockIdx.x, n = blockIdx.y + first_frame;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool trunc = n > cxt + 1;
+  const int nf = trunc ? cxt + 1 : n;
+  const int lo = max(0, q - radius + 1), hi = min(N - 1, q + radius - 1);
+  const int bw = hi - lo + 1;
+  const int ncand = nf * bw;
+
+  float *qv = smem;                       // [C] (padded to a multiple of 4)
+  float *val = smem + ((C + 3) & ~3);     // [ncand]
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  __shared__ float sel_v[MAX_KNN];
+  __shared__ int sel_i[MAX_KNN];
+
+  for (int c = tid; c < C; c += 256) qv[c] = ehat[((long)n * N + q) * C + c];
+  __syncthreads();
+
+  // 16 lanes per candidate
+  const int sub = tid & 15, grp = tid >> 4;  // 16 groups per block
+  for (int cand = grp; cand < ncand; cand += 16) {
+    const int p = cand / bw, m = lo + cand % bw;
+    const int frame = trunc ? (p == 0 ? 0 : n - cxt + (p - 1)) : p;
+    const float *key = ehat + ((long)frame * N + m) * C;
+    float d = 0.f;
+    if ((C & 3) == 0) {
+      for (int c = 4 * sub; c < C; c += 64) {
+        const float4 kv = *reinterpret_cast<const float4 *>(key + c);
+        const float4 qq = *reinterpret_cast<const float4 *>(qv + c);
+        d += kv.x * qq.x + kv.y * qq.y + kv.z * qq.z + kv.w * qq.w;
+      }
+    } else {
+      for (int c = sub; c < C; c += 16) d += key[c] * qv[c];
+    }
+    d += __shfl_xor(d, 8);
+    d += __shfl_xor(d, 4);
+    d += __shfl_xor(d, 2);
+    d += __shfl_xor(d, 1);
+    if (sub == 0) val[cand] = d / temp;
+  }
+  __syncthreads();
+
+  // knn rounds of block-wide arg-max (ties -> lowest candidate index)
+  for (int j = 0; j < knn; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < ncand; c += 256) {
+      const float v = val[c];
+      if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+      sel_v[j] = bv;
+      sel_i[j] = bi;
+      if (bi != 0x7fffffff && bv != -INFINITY) val[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+
+  if (tid < knn) {
+    const float vmax = sel_v[0];  // in-band key m == q always exists (radius >= 1)
+    float ssum = 0.f;
+    for (int j = 0; j < knn; ++j) ssum += (sel_v[j] == -INFINITY) ? 0.f : expf(sel_v[j] - vmax);
+    const float v = sel_v[tid];
+    float w = 0.f;
+    int idx = 0;
+    if (v != -INFINITY) {
+      w = expf(v - vmax) / ssum;
+      const int c = sel_i[tid];
+      idx = (c / bw) * N + lo + c % bw;
+    }
+    const long o = ((long)(n - first_frame) * knn + tid) * N + q;
+    W[o] = w;
+    I[o] = idx;
+  }
+}
+
+__device__ inline float ld_l2(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void st_l2(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// single workgroup; frame n reads soft labels written for earlier frames by other waves of this
+// same workgroup: stores/loads are agent-scope (L2) and separated by vmcnt(0) + barrier.
+__global__ __launch_bounds__(1024) void labelprop_gather_kernel(const float *__restrict__ seed,
+                                                                const float *__restrict__ W,
+                                                                const int32_t *__restrict__ I, int T, int N, int M,
+                                                                int knn, int first_frame, float *L,
+                                                                float *__restrict__ pred) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (seed) {
+    for (int it = tid; it < N * M; it += nt) {
+      const int q = it / M, c = it % M;
+      st_l2(L + it, seed[q] == (float)c ? 1.f : 0.f);
+    }
+    for (int q = tid; q < N; q += nt) pred[(long)q * T] = seed[q];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int n = first_frame; n < T; ++n) {
+    const float *Wn = W + (long)(n - first_frame) * knn * N;
+    const int32_t *In = I + (long)(n - first_frame) * knn * N;
+    for (int it = tid; it < N * M; it += nt) {
+      const int q = it / M, c = it % M;
+      float p = 0.f;
+      for (int j = 0; j < knn; ++j) p += ld_l2(L + (long)In[j * N + q] * M + c) * Wn[j * N + q];
+      st_l2(L + ((long)n * N + q) * M + c, p);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int q = tid; q < N; q += nt) {
+      const float *row = L + ((long)n * N + q) * M;
+      float bv = ld_l2(row);
+      int bi = 0;
+      for (int c = 1; c < M; ++c) {
+        const float v = ld_l2(row + c);
+        if (v > bv) { bv = v; bi = c; }
+      }
+      pred[(long)q * T + n] = (float)bi;
+    }
+  }
+}
+
+// xent[a, i] = logsumexp_c A_i[c, a] - A_i[a, a],  A_i[c, a] = <ehat[i,c,0:C-1], ehat[i,a,1:C]> / 0.1
+__global__ __launch_bounds__(64) void xent_metric_kernel(const float *__restrict__ ehat, int T, int N, int C,
+                                                         float *__restrict__ xent) {
+  extern __shared__ float col[];  // [N]
+  const int a = blockIdx.x, i = blockIdx.y, lane = threadIdx.x;
+  const float *ea = ehat + ((long)i * N + a) * C + 1;
+  float m = -INFINITY;
+  for (int c = 0; c < N; ++c) {
+    const float *ec = ehat + ((long)i * N + c) * C;
+    float d = 0.f;
+    for (int ch = lane; ch < C - 1; ch += 64) d += ec[ch] * ea[ch];
+    d = wave_sum(d) / 0.1f;
+    if (lane == 0) col[c] = d;
+    m = fmaxf(m, d);
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += expf(col[c] - m);
+  s = wave_sum(s);
+  if (lane == 0) xent[(long)a * (T - 1) + i] = (logf(s) + m) - col[a];
+}
+
+}  // namespace
+}  // namespace crw
+
+using namespace crw;
+
+extern "C" {
+
+int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp, int knn,
+                       int first_frame, float *W, int32_t *I, crw_stream_t stream) {
+  if (!ehat || !W || !I || T < 2 || N < 1 || C < 1 || cxt_size < 1 || radius < 1 || knn < 1 || knn > MAX_KNN ||
+      !(temp > 0.f) || first_frame < 1 || first_frame >= T)
+    return CRW_EINVAL;
+  const long max_nf = (long)(cxt_size + 1 < T - 1 ? cxt_size + 1 : T - 1);
+  const long max_bw = (2L * radius - 1 < N) ? 2L * radius - 1 : N;
+  const size_t lds = (((size_t)C + 3) & ~(size_t)3) * 4 + (size_t)(max_nf * max_bw) * 4;
+  if (lds > 60 * 1024) return CRW_EINVAL;
+  hipLaunchKernelGGL(labelprop_topk_kernel, dim3(N, T - first_frame), dim3(256), lds, (hipStream_t)stream, ehat, T,
+                     N, C, cxt_size, radius, temp, knn, first_frame, W, I);
+  return check_launch();
+}
+
+int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn,
+                         int first_frame, float *L, float *pred, crw_stream_t stream) {
+  if (!W || !I || !L || !pred || T < 2 || N < 1 || M < 1 || knn < 1 || first_frame < 1 || first_frame >= T ||
+      (!seed && first_frame < 1))
+    return CRW_EINVAL;
+  hipLaunchKernelGGL(labelprop_gather_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seed, W, I, T, N, M, knn,
+                     first_frame, L, pred);
+  return check_launch();
+}
+
+int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream) {
+  if (!ehat || !xent || T < 2 || N < 1 || C < 2 || (size_t)N * 4 > 60 * 1024) return CRW_EINVAL;
+  hipLaunchKernelGGL(xent_metric_kernel, dim3(N, T - 1), dim3(64), (size_t)N * 4, (hipStream_t)stream, ehat, T, N, C,
+                     xent);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -275,6 +275,20 @@ def run_dataset_case(ref_dataset, name, H, W, length, dim, overlap, seed):
     print(f"{name}: n_items={n} item{items.shape[1:]}")
 
 
+def run_resnet_case(ref_encoder, name, seed):
+    torch.manual_seed(seed)
+    net = ref_encoder.Resnet(False)
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(6, 1, 16, 16, generator=gen)
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    np.savez(os.path.join(HERE, name + ".npz"), keys=np.array(list(sd.keys())),
+             sums=np.array([float(v.double().sum()) for v in sd.values()]), x=x.numpy(), y_eval=y.numpy())
+    print(f"{name}: {len(sd)} keys, out{tuple(y.shape)}")
+
+
 def main():
     torch.set_num_threads(8)
     ref_model, ref_encoder, ref_utils, ref_dataset, ref_lp = import_reference()
@@ -300,6 +314,7 @@ def main():
                        dict(CXT_SIZE=8, RADIUS=6, TEMP=0.05, KNN=10), True, 33)
     run_labelprop_case(ref_utils, ref_lp, "labelprop_mc1_T100N12", 100, 12, 32, 4,
                        dict(CXT_SIZE=80, RADIUS=10, TEMP=0.01, KNN=10), False, 34)
+    run_resnet_case(ref_encoder, "resnet_seed11", 11)
     # dataset unfold
     run_dataset_case(ref_dataset, "dataset_64x256", 64, 256, 8, (16, 16), (8, 0), 41)
     run_dataset_case(ref_dataset, "dataset_50x200_ow", 50, 200, 5, (12, 10), (4, 2), 42)

@@ -1,0 +1,191 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the golden vectors of the
+reference and against the CPU oracle on seeded inputs.  Tolerance: north_star asks for 1e-4 fp32
+on the loss and propagated label map; label maps are compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import crw_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+WALK_CASES = ["walk_cfg1_B2T8N7", "walk_odd_B1T4N5", "walk_onecycle_B3T3N6", "walk_cfg2_B1T16N63",
+              "walk_N70_B2T6", "walk_cfg3_B1T32N63", "walk_noise_B2T8N7_tau0p1"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import crw_hip
+    crw_hip.lib()
+    assert torch.cuda.is_available()
+    return crw_hip
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("n,batch", [(32, 3), (64, 2), (96, 1), (128, 2), (192, 1), (256, 9), (512, 2), (1152, 1)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_f32_matches_torch(hip, n, batch, ta, tb):
+    g = torch.Generator().manual_seed(n + 7 * ta + 3 * tb)
+    A = torch.randn(batch, n, n, generator=g).cuda()
+    B = torch.randn(batch, n, n, generator=g).cuda()
+    C0 = torch.randn(batch, n, n, generator=g).cuda()
+    ref = (A.transpose(1, 2) if ta else A).double() @ (B.transpose(1, 2) if tb else B).double()
+    out = hip.gemm_f32(A, B, transA=ta, transB=tb)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5 * n ** 0.5)
+    acc = hip.gemm_f32(A, B, C0.clone(), transA=ta, transB=tb, beta=True)
+    torch.testing.assert_close(acc.double(), ref + C0.double(), rtol=1e-5, atol=1e-5 * n ** 0.5)
+
+
+@pytest.mark.parametrize("name", WALK_CASES)
+def test_training_path_matches_reference(hip, name):
+    import model as crw_model
+    g = load_golden(name)
+    tau = float(g["tau"])
+    emb = dev(g["emb"]).requires_grad_(True)
+    A = crw_model.affinity(emb, tau)
+    np.testing.assert_allclose(A.detach().cpu().numpy(), g["A"], rtol=1e-4, atol=1e-4 / tau * 1e-2)
+    loss, state, At = hip.walk_fwd(A.detach().contiguous(), want_At=True)
+    np.testing.assert_allclose(At.cpu().numpy(), g["At"], rtol=1e-4, atol=1e-6)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    loss2 = crw_model.walk_loss(A)
+    assert loss2.item() == loss.item()  # deterministic
+    loss2.backward()
+    scale = np.abs(g["demb"]).max()
+    np.testing.assert_allclose(emb.grad.cpu().numpy(), g["demb"], rtol=2e-3, atol=2e-4 * scale)
+
+
+def test_no_cycle_T2(hip):
+    import model as crw_model
+    g = load_golden("walk_T2_nocycle")
+    emb = dev(g["emb"]).requires_grad_(True)
+    A = crw_model.affinity(emb, float(g["tau"]))
+    np.testing.assert_allclose(A.detach().cpu().numpy(), g["A"], rtol=1e-4, atol=1e-4)
+    loss = crw_model.walk_loss(A)
+    assert loss.item() == 0.0
+    loss.backward()
+    assert torch.count_nonzero(emb.grad).item() == 0
+
+
+@pytest.mark.parametrize("B,T,N,C,tau", [(2, 5, 100, 64, 0.05), (1, 4, 130, 32, 0.1), (1, 3, 200, 128, 0.02),
+                                         (3, 6, 33, 20, 0.07), (1, 5, 257, 16, 0.2)])
+def test_training_path_matches_oracle_seeded(hip, B, T, N, C, tau):
+    import model as crw_model
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    base = torch.randn(1, 1, N, C, generator=g)
+    emb_cpu = (base + 0.4 * torch.randn(B, T, N, C, generator=g)).float()
+    o = orc.crw_from_features(emb_cpu.numpy(), tau, np.float64)
+    emb = emb_cpu.cuda().requires_grad_(True)
+    A = crw_model.affinity(emb, tau)
+    np.testing.assert_allclose(A.detach().cpu().numpy(), o["A"], rtol=1e-4, atol=1e-4)
+    loss, _, At = hip.walk_fwd(A.detach().contiguous(), want_At=True)
+    np.testing.assert_allclose(At.cpu().numpy(), o["At"], rtol=1e-4, atol=1e-6)
+    assert abs(loss.item() - float(o["loss"])) <= 1e-4
+    crw_model.walk_loss(A).backward()
+    np.testing.assert_allclose(emb.grad.cpu().numpy(), o["demb"], rtol=2e-3, atol=2e-4 * np.abs(o["demb"]).max())
+
+
+def test_walk_backward_dA_matches_oracle(hip):
+    g = torch.Generator().manual_seed(5)
+    A_cpu = (torch.randn(2, 6, 40, 40, generator=g) * 3).float()
+    dA_ref = orc.walk_backward(A_cpu.double().numpy(), gloss=0.7)
+    A = A_cpu.cuda()
+    loss, state, _ = hip.walk_fwd(A)
+    dA = hip.walk_bwd(torch.tensor(0.7).cuda(), state, 2, 7, 40)
+    np.testing.assert_allclose(dA.cpu().numpy(), dA_ref, rtol=1e-3, atol=1e-4 * np.abs(dA_ref).max())
+    # A_{T-2} never enters the loss
+    assert torch.count_nonzero(dA[:, -1]).item() == 0
+
+
+@pytest.mark.parametrize("name,wname", [("cnn_cfg1_B2T8N7", "cnn_weights_seed11"),
+                                        ("cnn_posembed_B1T4N3", "cnn_weights_posembed_seed21")])
+def test_full_model_matches_reference(hip, name, wname):
+    import model as crw_model
+    import encoder as crw_encoder
+    g, w = load_golden(name), load_golden(wname)
+    torch.backends.cudnn.allow_tf32 = False
+    enc = crw_encoder.CNN(bool(g["pos_embed"]))
+    enc.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    net = crw_model.CRW(enc, float(g["tau"]), bool(g["pos_embed"])).cuda()
+    loss, A = net(dev(g["seq"]))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    np.testing.assert_allclose(A.detach().cpu().numpy(), g["A"], rtol=1e-3, atol=5e-3)
+    loss.backward()
+    for k, p in enc.named_parameters():
+        ref = g["grad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max())
+    assert crw_model.CRW(enc, 0.01, bool(g["pos_embed"]), only_a=True).cuda()(dev(g["seq"])).shape == A.shape
+
+
+LP_CASES = ["labelprop_trunc_T14N10", "labelprop_full_T40N48", "labelprop_last_T20N24", "labelprop_mc1_T100N12"]
+
+
+class _Flatten(torch.nn.Module):
+    def forward(self, x):
+        return x.flatten(1)
+
+
+@pytest.mark.parametrize("name", LP_CASES)
+def test_propagate_matches_reference(hip, name):
+    import utils as crw_utils
+    from imported.labelprop import LabelPropVOS_CRW
+    g = load_golden(name)
+    T, N, C = g["emb"].shape
+    cfg = dict(CXT_SIZE=int(g["cxt_size"]), RADIUS=int(g["radius"]), TEMP=float(g["temp"]), KNN=int(g["knn"]))
+    seq = dev(g["emb"]).reshape(T, N, C // 4, 4)
+    pred, xent, change_idx = crw_utils.propagate(seq, dev(g["seg_ref"]), _Flatten(), LabelPropVOS_CRW(cfg),
+                                                 int(g["nclasses"]), False, bool(g["use_last"]))
+    assert pred.shape == (N, T) and xent.shape == (N, T - 1) and not xent.is_cuda
+    assert np.array_equal(pred.cpu().numpy(), g["pred"]), f"{(pred.cpu().numpy() != g['pred']).sum()} labels differ"
+    np.testing.assert_allclose(xent.numpy(), g["xent"], rtol=1e-4, atol=1e-4)
+
+
+def test_predict_frame_by_frame_equals_batched(hip):
+    from imported.labelprop import LabelPropVOS_CRW
+    g = load_golden("labelprop_trunc_T14N10")
+    T, N, C = g["emb"].shape
+    M = int(g["nclasses"])
+    cfg = dict(CXT_SIZE=int(g["cxt_size"]), RADIUS=int(g["radius"]), TEMP=float(g["temp"]), KNN=int(g["knn"]))
+    feats = hip.normalize(dev(g["emb"]))
+    seed = dev(orc.seed_labels(g["seg_ref"], N))
+    pred_all, L = LabelPropVOS_CRW(cfg).propagate_all(feats, seed, M)
+    lp = LabelPropVOS_CRW(cfg)
+    as_feat = lambda n: feats[n].t()[None, :, :, None]
+    fl = [as_feat(0)]
+    ml = [(seed[None, :] == torch.arange(M).cuda()[:, None]).float()[None, :, :, None]]
+    for n in range(1, T):
+        m = lp.predict(fl, ml, as_feat(n))
+        assert m.shape == (1, M, N, 1)
+        torch.testing.assert_close(m[0, :, :, 0].t(), L[n * N:(n + 1) * N], rtol=0, atol=0)
+        fl.append(as_feat(n))
+        ml.append(m)
+    assert np.array_equal(pred_all.cpu().numpy(), g["pred"])
+    assert lp.mask.shape == (1, N, N) and lp.mask_hw == (N, 1)
+
+
+def test_labelprop_matches_oracle_mcords_shape(hip):
+    """BASELINE config 5 shape [T,N] = [256,48] with truncation (CXT_SIZE=80)."""
+    from imported.labelprop import LabelPropVOS_CRW
+    g = torch.Generator().manual_seed(77)
+    T, N, C, M = 256, 48, 128, 4
+    proto = torch.randn(N + 16, C, generator=g)
+    t = torch.arange(T).float()
+    depth = torch.arange(N).float()[None] + 3 * torch.sin(2 * np.pi * t / 40)[:, None] + 6
+    lo = depth.floor().long()
+    fr = (depth - lo.float()).unsqueeze(-1)
+    emb = (proto[lo] * (1 - fr) + proto[lo + 1] * fr + 0.3 * torch.randn(T, N, C, generator=g)).float()
+    seed = (torch.arange(N) * M // N).float()
+    ref = orc.labelprop(emb.numpy(), seed.numpy(), M, 80, 10, 0.1, 20)
+    feats = hip.normalize(emb.cuda())
+    pred, _ = LabelPropVOS_CRW(dict(CXT_SIZE=80, RADIUS=10, TEMP=0.1, KNN=20)).propagate_all(feats, seed.cuda(), M)
+    mism = (pred.cpu().numpy() != ref).sum()
+    assert mism == 0, f"{mism} of {ref.size} labels differ"
+
+
+def test_no_cpu_fallback(hip):
+    import model as crw_model
+    with pytest.raises(RuntimeError):
+        crw_model.affinity(torch.randn(1, 3, 4, 8), 0.1)

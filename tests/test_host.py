@@ -1,0 +1,138 @@
+"""CPU-side tests: host logic, class surface, C-ABI library loads and exports what the header declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, PKG, load_golden
+from oracle import crw_oracle as orc
+
+
+def test_library_exports_every_declared_symbol():
+    import crw_hip
+    if not os.path.exists(crw_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    handle = ctypes.CDLL(crw_hip.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "crw_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(crw_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in crw_hip.h but not exported"
+    assert declared == set(crw_hip.SIGNATURES), declared ^ set(crw_hip.SIGNATURES)
+    lib = crw_hip.lib()
+    assert lib.crw_abi_version() == 1 and lib.crw_build_arch() == b"gfx950"
+    # pure host-side geometry queries
+    assert [lib.crw_padded_nodes(n) for n in (1, 7, 63, 64, 65, 128, 129, 497, 1024, 1025, 4096)] == \
+        [32, 32, 64, 64, 96, 128, 192, 512, 1024, 1152, 4096]
+    assert lib.crw_walk_state_bytes(1, 2, 8) == 256
+    s1, s2 = lib.crw_walk_state_bytes(1, 32, 63), lib.crw_walk_state_bytes(2, 32, 63)
+    assert 0 < s1 < s2 <= 2 * s1
+
+
+def test_cpu_tensors_are_refused():
+    import crw_hip
+    import model as crw_model
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        crw_model.affinity(torch.randn(1, 3, 4, 8), 0.1)
+    with pytest.raises(RuntimeError):
+        crw_hip.normalize(torch.randn(4, 8))
+
+
+def test_cnn_surface_and_seeded_init_match_reference():
+    import encoder as crw_encoder
+    w = load_golden("cnn_weights_seed11")
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == list(w.keys())
+    assert sum(p.numel() for p in enc.parameters()) == 263088
+    for k in w:
+        assert np.array_equal(sd[k].numpy(), w[k]), k
+    wp = load_golden("cnn_weights_posembed_seed21")
+    torch.manual_seed(21)
+    encp = crw_encoder.CNN(True)
+    for k in wp:
+        assert np.array_equal(encp.state_dict()[k].numpy(), wp[k]), k
+    g = load_golden("cnn_cfg1_B2T8N7")
+    B, T, N, h, w_ = g["seq"].shape
+    with torch.no_grad():
+        out = enc(torch.tensor(g["seq"]).reshape(-1, 1, h, w_))
+    np.testing.assert_allclose(out.reshape(B, T, N, -1).numpy(), g["emb"], rtol=1e-4, atol=1e-5)
+
+
+def test_resnet_surface_matches_reference():
+    import encoder as crw_encoder
+    g = load_golden("resnet_seed11")
+    torch.manual_seed(11)
+    net = crw_encoder.Resnet(False)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert sum(p.numel() for p in net.parameters()) == 4971468
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    np.testing.assert_allclose(sums, g["sums"], rtol=1e-6, atol=1e-6)
+    net.eval()
+    with torch.no_grad():
+        out = net(torch.tensor(g["x"]))
+    np.testing.assert_allclose(out.numpy(), g["y_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_pos_embed_and_ndiag():
+    import utils as crw_utils
+    x = torch.randn(5, 1, 6, 4)
+    y = crw_utils.pos_embed(x)
+    assert y.shape == (5, 2, 6, 4)
+    assert torch.equal(y[:, 1], x[:, 0])
+    assert torch.allclose(y[0, 0, :, 0], torch.arange(6) / 6 - 0.5)
+    assert torch.equal(y, orc.pos_embed(x))
+    assert torch.equal(crw_utils.ndiag_matrix(5, 1), torch.eye(5))
+    m = crw_utils.ndiag_matrix(5, 3)
+    assert torch.allclose(m.sum(1), torch.ones(5)) and m[0, 1] > 0 and m[0, 2] == 0
+    seg = torch.tensor(load_golden("labelprop_trunc_T14N10")["seg_ref"])
+    assert np.array_equal(crw_utils.seed_labels(seg, 10).numpy(), orc.seed_labels(seg.numpy(), 10))
+
+
+@pytest.mark.parametrize("name", ["dataset_64x256", "dataset_50x200_ow"])
+def test_dataset_matches_reference(name):
+    import dataset as crw_dataset
+    g = load_golden(name)
+    dim, ov, L = tuple(int(x) for x in g["dim"]), tuple(int(x) for x in g["overlap"]), int(g["length"])
+    ds = crw_dataset.RGDataset.from_tensor(torch.tensor(g["rg"]), L, dim, ov)
+    assert len(ds) == int(g["n_items"])
+    for i, idx in enumerate(g["picks"]):
+        item = ds[int(idx)]
+        assert item.dtype == torch.float32 and np.array_equal(item.numpy(), g["items"][i])
+    short = ds.get_smaller_item(0, 2)
+    assert short.shape[0] == 2 and ds.pxw == 2 * dim[1] - ov[1]
+
+
+def test_create_dataset_synthetic_and_model_factory():
+    import utils as crw_utils
+    import encoder as crw_encoder
+    full = crw_utils.create_dataset(0, 8, (16, 16), (8, 0), full=True, synthetic=(64, 256))
+    sub = crw_utils.create_dataset(0, 8, (16, 16), (8, 0), full=False, synthetic=(64, 256))
+    assert len(full) == 9 and len(sub) == 2 and full[0].shape == (8, 7, 16, 16)
+    assert isinstance(crw_utils.create_model(0, False), crw_encoder.CNN)
+    assert isinstance(crw_utils.create_model(1, True), crw_encoder.Resnet)
+
+
+def test_crw_constructor_surface():
+    import model as crw_model
+    enc = torch.nn.Identity()
+    m = crw_model.CRW(enc, 0.01, False)
+    assert (m.encoder, m.tau, m.pos_embed, m.only_a) == (enc, 0.01, False, False)
+    assert list(m.parameters()) == []
+    assert crw_model.CRW(enc, 0.1, True, only_a=True).only_a
+
+
+def test_labelprop_config_surface():
+    from imported.labelprop import LabelPropVOS_CRW
+    lp = LabelPropVOS_CRW(dict(CXT_SIZE=4, RADIUS=3, TEMP=0.1, KNN=5))
+    assert (lp.cxt_size, lp.radius, lp.temperature, lp.topk, lp.mask, lp.mask_hw) == (4, 3, 0.1, 5, None, None)
+    assert lp.context_index(0, 6) == [0, 2, 3, 4, 5]
+    m = lp._band(6, 1, torch.device("cpu"))
+    assert np.array_equal(m[0].numpy(), orc.band_bias(6, 3))
