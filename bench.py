@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the CRW training step (BASELINE.json metric: radargram columns/sec, CRW fwd+bwd,
+512x4096 sequences).
+
+  python bench.py [--gpus N --steps K --warmup W]        (N > 1: launched by torch.distributed.run)
+
+A "step" = one synthetic 512x4096 radargram per GPU = 8 non-overlapping items [T=32, N=63, 16x16]
+(patch 16x16, overlap (8,0), reference defaults) -> encoder fwd, normalise+affinity, dual softmax,
+transition chain, loss, full backward to the encoder weight gradients, ONE all-reduce of the flat
+gradient (N > 1) and the Adam update.  Inputs are resident in HBM before the timed region.
+Rank 0 prints one JSON line.  Weak scaling: each rank processes its own radargram.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "radar-sounder-crw_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+PEAK_HBM_GBS = 8000.0
+
+H_RG, W_RG, T_SEQ, PATCH, OVERLAP, TAU = 512, 4096, 32, (16, 16), (8, 0), 0.01
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", type=int, default=0, help="0 = CNN (BASELINE 'tiny CNN encoder'), 1 = Resnet")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def make_batch(rank, device):
+    import dataset as crw_dataset
+    ds = crw_dataset.RGDataset.synthetic(H_RG, W_RG, T_SEQ, PATCH, OVERLAP, seed=11 + rank)
+    items = [ds[i] for i in range(0, len(ds), T_SEQ)]  # non-overlapping items of one radargram
+    return torch.stack(items).contiguous().to(device)  # [8, 32, 63, 16, 16]
+
+
+def chain_probe(n, batch, nprob, iters=50):
+    """Average duration of one grouped chain-GEMM launch (crw_gemm_f32 = the kernel of
+    crw_walk_fwd/bwd) at padded size n, measured with HIP events on the launch stream."""
+    import crw_hip
+    A = torch.rand(batch * nprob, n, n, device="cuda")
+    Bm = torch.rand(batch * nprob, n, n, device="cuda")
+    C = torch.empty_like(A)
+    for _ in range(3):
+        crw_hip.gemm_f32(A, Bm, C)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        crw_hip.gemm_f32(A, Bm, C)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * n ** 3 * batch * nprob
+    return ms, flops
+
+
+def cpu_baseline(budget_s):
+    """The oracle (pure torch-CPU restatement, validated against the reference) timed on this
+    box's host cores on a bounded sample of the same workload: ONE item [1,32,63,16,16] per step."""
+    import numpy as np
+    from oracle import crw_oracle as orc
+    import encoder as crw_encoder
+    import dataset as crw_dataset
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    ds = crw_dataset.RGDataset.synthetic(H_RG, W_RG, T_SEQ, PATCH, OVERLAP, seed=11)
+    seq = ds[0][None].contiguous()
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        loss, _, _ = orc.crw_forward_torch(seq, sd, TAU)
+        loss.backward()
+
+    # the box exposes more hardware threads than this job's CPU share: time the step at a few
+    # thread counts and report the fastest (cores = threads actually used for that figure)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    candidates = sorted({min(avail, c) for c in (16, 32, avail)})
+    best = None
+    for threads in candidates:
+        torch.set_num_threads(threads)
+        step()  # warm-up
+        times = []
+        t_end = time.time() + budget_s / len(candidates)
+        while len(times) < 3 or (time.time() < t_end and len(times) < 30):
+            t0 = time.time()
+            step()
+            times.append(time.time() - t0)
+        med = float(np.median(times))
+        if best is None or med < best[0]:
+            best = (med, threads, len(times))
+    med, threads, n = best
+    cols = T_SEQ * PATCH[1]
+    return {"value": cols / med, "unit": "radargram columns/s", "cores": threads, "kind": "port",
+            "sample": f"1 item [1,{T_SEQ},63,16,16] fwd+bwd per step, median of {n} steps ({med:.3f} s/step) at "
+                      f"{threads} threads (fastest of {candidates}; {avail} hw threads visible), "
+                      f"torch {torch.__version__} CPU ops"}
+
+
+def main():
+    args = parse()
+    import dist as crw_dist
+    rank, world, local = crw_dist.init_from_env("nccl")
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import crw_hip
+    import model as crw_model
+    import utils as crw_utils
+    crw_hip.lib()
+
+    torch.manual_seed(11)
+    enc = crw_utils.create_model(args.model, False)
+    net = crw_model.CRW(enc, TAU, False).to(device)
+    net.train(True)
+    bucket = crw_dist.FlatGradBucket(net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, foreach=True)
+    seq = make_batch(rank, device)
+    B, T, N = seq.shape[:3]
+    cols_per_step = B * (T * (PATCH[1] - OVERLAP[1]) + OVERLAP[1])
+
+    def step():
+        bucket.zero()
+        loss, _ = net(seq)
+        loss.backward()
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "radargram columns/sec (CRW fwd+bwd)", "value": cols_per_step * world / (elapsed / args.steps),
+            "unit": "radargram columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
+                                   f"[T={T},N={N},16x16] (patch 16x16, overlap (8,0)), tau={TAU}, "
+                                   f"{'CNN' if args.model == 0 else 'Resnet'} encoder, fwd+bwd+all-reduce+Adam",
+                       "columns_per_step_per_gpu": cols_per_step, "parallelism": f"dp{world} (independent sequences)",
+                       "chain": "fp32 MFMA 16x16x4, prefix form", "loss": final_loss},
+        }
+        if not args.no_probe:
+            Np = crw_hip.padded_nodes(N)
+            pms, pfl = chain_probe(Np, B, 3)
+            out["roofline"] = {"kernel": "gemm_pad_f32_kernel (transition chain, one walk step = 3 products x B)",
+                               "bound": "mfma", "achieved": pfl / (pms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f32"],
+                               "unit": "TFLOP/s", "frac": pfl / (pms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"],
+                               "traffic": None, "launch_us": pms * 1e3, "shape": f"n={Np} batch={B}x3"}
+            kms, kfl = chain_probe(4096, 1, 3, iters=5)
+            out["roofline_chain_n4096"] = {"kernel": "gemm_pad_f32_kernel", "bound": "mfma",
+                                           "achieved": kfl / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f32"],
+                                           "unit": "TFLOP/s", "frac": kfl / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"],
+                                           "traffic": None, "launch_us": kms * 1e3, "shape": "n=4096 batch=1x3"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

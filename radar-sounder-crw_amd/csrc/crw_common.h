@@ -16,6 +16,11 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 extern thread_local int g_last_hip_error;
 
+// HIP keeps a per-thread "last error" that other users of the runtime in this process (PyTorch,
+// MIOpen) may leave set; entry points drop it before their first launch so that check_launch()
+// only reports errors of our own launches.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -267,6 +267,7 @@ int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s) {
 
 extern "C" int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
                             int beta, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!A || !B || !C) return CRW_EINVAL;
   crw::GemmGroup g{};
   g.nprob = 1;

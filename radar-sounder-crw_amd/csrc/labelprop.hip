@@ -188,6 +188,7 @@ extern "C" {
 
 int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp, int knn,
                        int first_frame, float *W, int32_t *I, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!ehat || !W || !I || T < 2 || N < 1 || C < 1 || cxt_size < 1 || radius < 1 || knn < 1 || knn > MAX_KNN ||
       !(temp > 0.f) || first_frame < 1 || first_frame >= T)
     return CRW_EINVAL;
@@ -202,6 +203,7 @@ int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int
 
 int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn,
                          int first_frame, float *L, float *pred, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!W || !I || !L || !pred || T < 2 || N < 1 || M < 1 || knn < 1 || first_frame < 1 || first_frame >= T ||
       (!seed && first_frame < 1))
     return CRW_EINVAL;
@@ -211,6 +213,7 @@ int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, in
 }
 
 int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!ehat || !xent || T < 2 || N < 1 || C < 2 || (size_t)N * 4 > 60 * 1024) return CRW_EINVAL;
   hipLaunchKernelGGL(xent_metric_kernel, dim3(N, T - 1), dim3(64), (size_t)N * 4, (hipStream_t)stream, ehat, T, N, C,
                      xent);

@@ -116,6 +116,7 @@ size_t crw_walk_scratch_bytes(int B, int T, int N) {
 }
 
 int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!emb || !ehat || rows < 1 || C < 1) return CRW_EINVAL;
   hipLaunchKernelGGL(normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb, (long)rows, C,
                      ehat, norm);
@@ -124,6 +125,7 @@ int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, c
 
 int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau, float *ehat, float *norm, float *A,
                      crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!emb || !ehat || !norm || !A || bad_shape(B, T, N) || C < 1 || !(tau > 0.f)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   CRW_TRY(crw_normalize(emb, B * T * N, C, ehat, norm, stream));
@@ -144,6 +146,7 @@ int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau, fl
 
 int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, size_t state_bytes, float *At_out,
                  float *loss, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!A || !loss || bad_shape(B, T, N)) return CRW_EINVAL;
   if (chain != CRW_CHAIN_F32) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -189,6 +192,7 @@ int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, si
 
 int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state, size_t state_bytes, void *scratch,
                  size_t scratch_bytes, float *dA, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!gloss || !dA || bad_shape(B, T, N)) return CRW_EINVAL;
   if (chain != CRW_CHAIN_F32) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -242,6 +246,7 @@ int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state
 
 int crw_affinity_bwd(const float *dA, const float *ehat, const float *norm, int B, int T, int N, int C, float tau,
                      float *dehat_ws, float *demb, crw_stream_t stream) {
+  crw::clear_stale_error();
   if (!dA || !ehat || !norm || !dehat_ws || !demb || bad_shape(B, T, N) || C < 1 || !(tau > 0.f)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long NC = (long)N * C, NN = (long)N * N;
