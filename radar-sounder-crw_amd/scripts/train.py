@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""CRW training entrypoint -- same flags and defaults as the reference's scripts/train.py:17-37
+(--tune and the Ray-Tune branch are out of scope: third-party orchestration, SURVEY.md section 2
+row 10).  Additions: --data_path / --synthetic H W (the reference's dataset paths are private),
+--steps (stop early), --save (skip writing the checkpoint when empty).
+
+Single GPU:   python radar-sounder-crw_amd/scripts/train.py --model 0 --synthetic 512 4096
+Multi GPU:    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+                  radar-sounder-crw_amd/scripts/train.py --model 0 --synthetic 512 32768
+One process per GPU; items (independent sequences) are sharded over ranks and the only exchange is
+one RCCL all-reduce of the flat encoder gradient per step (the reference instead wraps the encoder
+in nn.DataParallel and runs the walk on GPU 0, scripts/train.py:45-47).
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+from torch.optim import Adam
+from torch.utils.data import DataLoader, Subset
+
+from utils import create_model, create_dataset
+from model import CRW
+import dist as crw_dist
+
+torch.manual_seed(11)
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser('CRW Train', add_help=True)
+    p.add_argument('--tune', default=False, type=bool, help='Ray Tune search (not supported here)')
+    p.add_argument('--model', default=1, type=int, help='0=CNN,1=Resnet18')
+    p.add_argument('--dataset', default=3, type=int, help='0=MCORDS1,1=Miguel,3=SHARAD')
+    p.add_argument('--patch_size', default=(16, 16), nargs=2, type=int)
+    p.add_argument('--seq_length', default=20, type=int)
+    p.add_argument('--overlap', default=(8, 0), nargs='+', type=int)
+    p.add_argument('--batch_size', default=8, type=int, help='global batch (items per step over all ranks)')
+    p.add_argument('--epochs', default=2, type=int)
+    p.add_argument('--lr', default=1E-3, type=float)
+    p.add_argument('--tau', default=0.01, type=float)
+    p.add_argument('--pos_embed', default=False, type=bool)
+    p.add_argument('--dataset_full', default=True)
+    p.add_argument('--output_folder', default='./resources/')
+    p.add_argument('--output_name', default='sharad16_3')
+    p.add_argument('--data_path', default=None, help='H x W radargram .pt file')
+    p.add_argument('--synthetic', default=None, nargs=2, type=int, metavar=('H', 'W'))
+    p.add_argument('--steps', default=0, type=int, help='stop after this many steps (0 = full epochs)')
+    p.add_argument('--save', default='', help='checkpoint path for encoder.state_dict() (default: '
+                                              '<output_folder>/models/<output_name>.pt)')
+    return p
+
+
+def main(args):
+    rank, world, local = crw_dist.init_from_env()
+    if rank == 0:
+        print(args)
+    if args.tune:
+        raise SystemExit('--tune (Ray Tune) is outside the scope of the MI355X build')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    encoder = create_model(args.model, args.pos_embed)  # same seed on every rank -> identical replicas
+    model = CRW(encoder, args.tau, args.pos_embed).to(device)
+    dataset = create_dataset(id=args.dataset, length=args.seq_length, dim=tuple(args.patch_size),
+                             full=args.dataset_full, overlap=tuple(args.overlap), data_path=args.data_path,
+                             synthetic=args.synthetic)
+    if args.batch_size % world:
+        raise SystemExit(f'--batch_size {args.batch_size} must be a multiple of the number of ranks ({world})')
+    per_rank = args.batch_size // world
+
+    optimizer = Adam(model.parameters(), lr=args.lr)
+    bucket = crw_dist.FlatGradBucket(model.parameters())
+    model.train(True)
+    loss_tot, nsteps = [], 0
+    for epoch in range(args.epochs):
+        t0 = time.time()
+        g = torch.Generator().manual_seed(11 + epoch)  # identical permutation on every rank
+        order = torch.randperm(len(dataset), generator=g).tolist()
+        usable = len(order) // args.batch_size * args.batch_size
+        mine = [order[i] for i in range(usable) if (i % args.batch_size) // per_rank == rank]
+        loader = DataLoader(Subset(dataset, mine), batch_size=per_rank, shuffle=False)
+        loss_epoch = []
+        for seq in loader:
+            seq = seq.to(device, non_blocking=True)
+            bucket.zero()
+            loss, _ = model(seq)
+            loss.backward()
+            bucket.all_reduce_mean()
+            optimizer.step()
+            loss_epoch.append(loss.detach())
+            nsteps += 1
+            if args.steps and nsteps >= args.steps:
+                break
+        mean = torch.stack(loss_epoch).mean() if loss_epoch else torch.zeros((), device=device)
+        if world > 1:
+            torch.distributed.all_reduce(mean, op=torch.distributed.ReduceOp.SUM)
+            mean /= world
+        loss_tot.append(mean.item())
+        cols = len(loss_epoch) * args.batch_size * (args.seq_length * (args.patch_size[1] - args.overlap[1])
+                                                   + args.overlap[1])
+        if rank == 0:
+            dt = time.time() - t0
+            print('Epoch:', epoch, 'Loss:', loss_tot[-1], 'Time:', dt, 'columns/s:', cols / max(dt, 1e-9))
+        if args.steps and nsteps >= args.steps:
+            break
+
+    if rank == 0:
+        path = args.save or os.path.join(args.output_folder, 'models', args.output_name + '.pt')
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(encoder.state_dict(), path)
+        print('Finished training.')
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return loss_tot
+
+
+if __name__ == '__main__':
+    a = get_args_parser().parse_args()
+    a.overlap = tuple(a.overlap)
+    main(a)
