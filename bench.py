@@ -69,6 +69,24 @@ def chain_probe(n, batch, nprob, iters=50):
     return ms, flops
 
 
+def chain_probe_bf16(n, batch, split, iters=10):
+    """Same probe for the bf16 matrix-core chain GEMM (operands already converted: GEMM time only)."""
+    import crw_hip
+    A = torch.rand(batch, n, n, device="cuda")
+    Bm = torch.rand(batch, n, n, device="cuda")
+    C, ws = crw_hip.gemm_bf16(A, Bm, split=split)
+    for _ in range(2):
+        crw_hip.gemm_bf16(A, Bm, C, split=split, ws=ws, convert=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        crw_hip.gemm_bf16(A, Bm, C, split=split, ws=ws, convert=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * n ** 3 * batch * (3 if split == 3 else 1)
+
+
 def cpu_baseline(budget_s):
     """The oracle (pure torch-CPU restatement, validated against the reference) timed on this
     box's host cores on a bounded sample of the same workload: ONE item [1,32,63,16,16] per step."""
@@ -188,6 +206,14 @@ def main():
                                            "achieved": kfl / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f32"],
                                            "unit": "TFLOP/s", "frac": kfl / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"],
                                            "traffic": None, "launch_us": kms * 1e3, "shape": "n=4096 batch=1x3"}
+            for split, key in ((1, "roofline_chain_n4096_bf16"), (3, "roofline_chain_n4096_bf16x3")):
+                bms, bfl = chain_probe_bf16(4096, 3, split)
+                out[key] = {"kernel": f"gemm_pad_bf16_kernel<{split}>", "bound": "mfma",
+                            "achieved": bfl / (bms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                            "frac": bfl / (bms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], "traffic": None,
+                            "launch_us": bms * 1e3, "shape": "n=4096 batch=3",
+                            "note": "MFMA flops executed" + (" (3 bf16 MFMAs per product: useful flops = 1/3)"
+                                                             if split == 3 else "")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -42,6 +42,7 @@ extern "C" {
 /* arithmetic used inside the transition-matrix chain */
 #define CRW_CHAIN_F32 0  /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32), parity path   */
 #define CRW_CHAIN_BF16 1 /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
+#define CRW_CHAIN_BF16X3 2 /* hi/lo bf16 operand pairs, 3 MFMAs per product: fp32-grade results */
 
 typedef void *crw_stream_t;
 
@@ -53,11 +54,11 @@ int crw_last_hip_error(void);       /* last hipError_t seen by this thread (0 = 
 /* geometry ------------------------------------------------------------------------------- */
 /* node count padded to the tile size of the chain GEMM (all internal NxN matrices are stored
  * [Np][Np] with zero padding). */
-int crw_padded_nodes(int N);
+int crw_padded_nodes(int N, int chain);
 /* bytes of the state buffer written by crw_walk_fwd and consumed by crw_walk_bwd */
-size_t crw_walk_state_bytes(int B, int T, int N);
+size_t crw_walk_state_bytes(int B, int T, int N, int chain);
 /* bytes of the scratch buffer needed by crw_walk_bwd */
-size_t crw_walk_scratch_bytes(int B, int T, int N);
+size_t crw_walk_scratch_bytes(int B, int T, int N, int chain);
 
 /* training path --------------------------------------------------------------------------- */
 /* emb [B,T,N,C] raw encoder output -> ehat [B,T,N,C] (L2-normalised, eps 1e-12),
@@ -68,7 +69,8 @@ int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau,
 /* A [B,T-1,N,N] -> loss[1] (= sum_k l_k / N, Appendix A.2 of SURVEY.md).
  * state: crw_walk_state_bytes(B,T,N) bytes, kept by the caller until crw_walk_bwd.
  * At_out: optional [B,T-2,N,N] copy of every per-cycle transition product (may be NULL).
- * chain: CRW_CHAIN_F32 | CRW_CHAIN_BF16.   T < 3 -> loss = 0. */
+ * chain: CRW_CHAIN_F32 | CRW_CHAIN_BF16 | CRW_CHAIN_BF16X3 (same value for fwd, bwd and the size
+ * queries).   T < 3 -> loss = 0. */
 int crw_walk_fwd(const float *A, int B, int T, int N, int chain,
                  void *state, size_t state_bytes, float *At_out, float *loss, crw_stream_t stream);
 
@@ -109,6 +111,14 @@ int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_str
 /* X [batch,n,n] (n multiple of 32, zero padded): C = op(A) * op(B) (+ C if beta), fp32 MFMA. */
 int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
                  int beta, crw_stream_t stream);
+
+/* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
+ * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous
+ * call, e.g. when timing the GEMM alone).  split = 1: plain bf16 operands; split = 3: hi/lo operand
+ * pairs, Ah*Bh + Ah*Bl + Al*Bh, fp32-grade result.  C fp32. */
+size_t crw_gemm_bf16_ws_bytes(int n, int batch, int split);
+int crw_gemm_bf16(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
+                  int beta, int split, void *ws, size_t ws_bytes, int convert, crw_stream_t stream);
 
 #ifdef __cplusplus
 }

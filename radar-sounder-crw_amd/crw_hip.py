@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrw_hip.so")
 
 CRW_OK, CRW_EINVAL, CRW_EWORKSPACE, CRW_EHIP = 0, 1, 2, 3
-CHAIN_F32, CHAIN_BF16 = 0, 1
+CHAIN_F32, CHAIN_BF16, CHAIN_BF16X3 = 0, 1, 2
 _ERR = {1: "CRW_EINVAL (bad shape / null pointer / unsupported size)",
         2: "CRW_EWORKSPACE (workspace too small)", 3: "CRW_EHIP (HIP launch failed)"}
 
@@ -24,9 +24,9 @@ SIGNATURES = {
     "crw_abi_version": (_c_int, []),
     "crw_build_arch": (ctypes.c_char_p, []),
     "crw_last_hip_error": (_c_int, []),
-    "crw_padded_nodes": (_c_int, [_c_int]),
-    "crw_walk_state_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "crw_walk_scratch_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_padded_nodes": (_c_int, [_c_int, _c_int]),
+    "crw_walk_state_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "crw_walk_scratch_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "crw_affinity_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p, _p]),
     "crw_walk_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _p, _p]),
     "crw_walk_bwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _c_sz, _p, _p]),
@@ -36,6 +36,8 @@ SIGNATURES = {
     "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
     "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
+    "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
 
 _lib = None
@@ -74,8 +76,8 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def padded_nodes(N):
-    return lib().crw_padded_nodes(N)
+def padded_nodes(N, chain=CHAIN_F32):
+    return lib().crw_padded_nodes(N, chain)
 
 
 # ------------------------------------------------------------------------------ training path
@@ -103,7 +105,7 @@ def walk_fwd(A, chain=CHAIN_F32, want_At=False):
     """A [B,T-1,N,N] -> (loss 0-d, state buffer, At [B,T-2,N,N] or None)."""
     B, Tm1, N, _ = A.shape
     T = Tm1 + 1
-    nbytes = lib().crw_walk_state_bytes(B, T, N)
+    nbytes = lib().crw_walk_state_bytes(B, T, N, chain)
     state = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
     loss = torch.empty((), dtype=torch.float32, device=A.device)
     At = torch.empty(B, max(T - 2, 0), N, N, device=A.device, dtype=torch.float32) if want_At else None
@@ -114,7 +116,7 @@ def walk_fwd(A, chain=CHAIN_F32, want_At=False):
 
 
 def walk_bwd(gloss, state, B, T, N, chain=CHAIN_F32):
-    nbytes = lib().crw_walk_scratch_bytes(B, T, N)
+    nbytes = lib().crw_walk_scratch_bytes(B, T, N, chain)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=state.device)
     dA = torch.empty(B, T - 1, N, N, device=state.device, dtype=torch.float32)
     g = gloss.reshape(1).to(torch.float32).contiguous()
@@ -167,3 +169,17 @@ def gemm_f32(A, B, C=None, transA=False, transB=False, beta=False):
     _check(lib().crw_gemm_f32(_dev(A, "A"), _dev(B, "B"), _dev(C, "C"), n, batch, int(transA), int(transB), int(beta),
                               _stream()), "crw_gemm_f32")
     return C
+
+
+def gemm_bf16(A, B, C=None, transA=False, transB=False, beta=False, split=1, ws=None, convert=True):
+    """bf16 matrix-core product of fp32 [batch,n,n] operands (n % 128 == 0); returns (C, ws)."""
+    batch, n, _ = A.shape
+    if C is None:
+        C = torch.empty_like(A)
+    nbytes = lib().crw_gemm_bf16_ws_bytes(n, batch, split)
+    if ws is None:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    _check(lib().crw_gemm_bf16(_dev(A, "A"), _dev(B, "B"), _dev(C, "C"), n, batch, int(transA), int(transB),
+                               int(beta), int(split), ctypes.c_void_p(ws.data_ptr()), ws.numel(), int(convert),
+                               _stream()), "crw_gemm_bf16")
+    return C, ws

@@ -62,10 +62,13 @@ __device__ inline float wave_sum(float v) {
 // ---- one product of a grouped, batched, zero-padded square GEMM ---------------------------
 // C[b] (+)= op(A[b]) * op(B[b]) [+ op(A2[b]) * op(B2[b])], all [n][n] row-major with ld = n.
 // op(X) = X^T when the matching flag is set.
+// fp32 kernel: A/B/A2/B2 are float*.  bf16 kernel: they are the bf16 "hi" images and Al/Bl/A2l/B2l
+// the "lo" images (split-3 only); Cb/Cbl receive bf16 hi/lo images of the result (optional).
 struct GemmProb {
   const void *A, *B, *A2, *B2;
-  float *C;
-  void *Cb;                  // optional bf16 shadow copy of C (bf16 chain), same layout
+  const void *Al, *Bl, *A2l, *B2l;
+  float *C;                  // fp32 result (bf16 kernel: optional)
+  void *Cb, *Cbl;
   long sA, sB, sA2, sB2, sC; // batch strides in elements
   int ta, tb, ta2, tb2;
   int beta;                  // 1: accumulate into the existing C
@@ -79,7 +82,8 @@ struct GemmGroup {
 };
 
 int launch_gemm_group_f32(const GemmGroup &g, hipStream_t s);
-int launch_gemm_group_bf16(const GemmGroup &g, hipStream_t s);
+int launch_gemm_group_bf16(const GemmGroup &g, int split, hipStream_t s);
+int launch_split_bf16(const float *x, long count, void *hi, void *lo, hipStream_t s);
 
 // general (bounds-checked) strided GEMM used by the affinity build and its backward:
 // C[b][m][n] = alpha_div ? acc / alpha : acc * alpha, acc = sum_k A(m,k) B(k,n) (+ second pair)

@@ -1,0 +1,374 @@
+// bf16 matrix-core GEMM for the transition-matrix chain (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+//   SPLIT = 1 : operands are bf16 images of the fp32 matrices (probabilities in [0,1]); 2.5 PF roof.
+//   SPLIT = 3 : every operand is a (hi, lo) pair of bf16 images, x = hi + lo to ~2^-17 relative;
+//               A*B ~= Ah*Bh + Ah*Bl + Al*Bh  (three MFMAs per fragment pair) -> fp32-grade
+//               results at a third of the bf16 rate, still ~5x the fp32-MFMA roof.
+//
+// Geometry: 128x128 output tile per 256-thread workgroup (2x2 waves of 64x64 = 4x4 MFMA tiles),
+// BK = 64, zero-padded square operands [n][n] (n multiple of 128) -> no edge handling.
+// HBM -> LDS goes through LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): the LDS
+// image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and again on
+// the read.  Two images, both 16 KiB:
+//   KC ("k-contiguous", operand stored [r][k]) : 128 rows x 128 B, chunk' = chunk ^ (row & 7),
+//        fragments by ds_read_b128;
+//   RC ("r-contiguous", operand stored [k][r]) :  64 rows x 256 B, chunk' = chunk ^ (((row&3)<<2)|((row>>2)&3)),
+//        fragments by two ds_read_b64_tr_b16 (hardware transpose), so transposed operands of the
+//        chain (Lt^T R, Gt^T dLt, ...) never need a transposed copy in HBM.
+// Double-buffered: the DMA of k-tile t+1 is in flight while the MFMAs of tile t run; one barrier
+// per k-tile.
+#include "crw_common.h"
+
+namespace crw {
+namespace {
+
+constexpr int BKB = 64;  // k-tile
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char *lds_cp;
+
+// byte offsets inside an image
+__device__ inline int kc_off(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
+__device__ inline int rc_sw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+template <int TB>
+__device__ inline int rc_off(int row, int chunk) { return row * (TB * 2) + 16 * (chunk ^ rc_sw(row)); }
+
+__device__ inline void glds16(const uint16_t *g, char *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// The transposed LDS read goes through inline asm: given the builtin, hipcc (ROCm 7.2) drains every
+// in-flight LDS-DMA (s_waitcnt vmcnt(0)) in front of it, which serialises the ring.  The caller
+// issues s_waitcnt lgkmcnt(0) + sched_barrier before the MFMAs that consume the result.
+__device__ inline s4v tr_read(uint32_t lds_addr) {
+  s4v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+__device__ inline uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(lds_cp)p; }
+
+// stage one image of an operand tile with TB rows (or TB columns): TB/8 pieces of 1 KiB
+//   KC: [TB rows][64 k]   128-byte rows, 8 rows per piece
+//   RC: [64 k rows][TB]   2*TB-byte rows, 512/TB rows per piece
+template <bool KC, int TB, int WAVES>
+__device__ inline void stage_image(const uint16_t *__restrict__ X, int ld, int r0, int k0, char *img, int wave,
+                                   int lane) {
+  constexpr int PIECES = TB / 8, PER = PIECES / WAVES;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int piece = WAVES * i + wave;
+    const uint16_t *src;
+    if (KC) {
+      const int row = 8 * piece + (lane >> 3);
+      const int chunk = (lane & 7) ^ (row & 7);
+      src = X + (long)(r0 + row) * ld + k0 + 8 * chunk;
+    } else {
+      constexpr int LPR = TB / 8;  // lanes (16-byte chunks) per row: 16 or 32
+      const int row = (64 / LPR) * piece + lane / LPR;
+      const int chunk = (lane % LPR) ^ rc_sw(row);
+      src = X + (long)(k0 + row) * ld + r0 + 8 * chunk;
+    }
+    glds16(src, img + piece * 1024);
+  }
+}
+
+// fragment of the 16 rows/cols [rb, rb+16) x k-step s (32 deep) of an image
+template <bool KC, int TB>
+__device__ inline bf8 read_frag(const char *img, int rb, int s, int lane) {
+  if (KC) {
+    const int row = rb + (lane & 15);
+    return *reinterpret_cast<const bf8 *>(img + kc_off(row, 4 * s + (lane >> 4)));
+  } else {
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+    const int row = 32 * s + 8 * g + q;
+    const int chunk = (rb >> 3) + (p >> 1);
+    const uint32_t base = lds_addr_of(img);
+    const s4v lo = tr_read(base + rc_off<TB>(row, chunk) + 8 * (p & 1));
+    const s4v hi = tr_read(base + rc_off<TB>(row + 4, chunk) + 8 * (p & 1));
+    const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf8, v);
+  }
+}
+
+struct BfOperand {
+  const uint16_t *hi, *lo;
+};
+
+// Tile configuration: TB x TB output tile, WAVES waves laid out WM x WN, each FM x FN MFMA tiles.
+template <int TB_>
+struct Cfg;
+template <>
+struct Cfg<128> { static constexpr int TB = 128, WAVES = 4, WN = 2, FM = 4, FN = 4; };
+template <>
+struct Cfg<256> { static constexpr int TB = 256, WAVES = 8, WN = 4, FM = 8, FN = 4; };
+
+template <int SPLIT, int TB, bool AKC, bool BKC>
+__device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0,
+                                int n0, char *lds, int wave, int lane) {
+  using C = Cfg<TB>;
+  constexpr int IMG = TB * 128;                 // bytes per image
+  constexpr int NIMG = (SPLIT == 3) ? 4 : 2;    // images per stage: A(hi[,lo]) B(hi[,lo])
+  constexpr int NSTAGE = (128 * 1024) / (NIMG * IMG) >= 4 ? 4 : 2;  // 128 KiB of LDS either way
+  constexpr int G = (TB / 8 / C::WAVES) * NIMG;  // LDS-DMA instructions per wave per k-tile
+  const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
+  const int nt = n / BKB;
+  auto stage = [&](int t, int buf) {
+    char *base = lds + buf * NIMG * IMG;
+    stage_image<AKC, TB, C::WAVES>(A.hi, n, m0, t * BKB, base, wave, lane);
+    stage_image<BKC, TB, C::WAVES>(B.hi, n, n0, t * BKB, base + IMG, wave, lane);
+    if (SPLIT == 3) {
+      stage_image<AKC, TB, C::WAVES>(A.lo, n, m0, t * BKB, base + 2 * IMG, wave, lane);
+      stage_image<BKC, TB, C::WAVES>(B.lo, n, n0, t * BKB, base + 3 * IMG, wave, lane);
+    }
+  };
+  // ring of NSTAGE buffers, DMA runs NSTAGE-1 k-tiles ahead of the MFMAs; counted vmcnt + raw
+  // s_barrier so the younger tiles stay in flight across the barrier (a __syncthreads() would
+  // drain them).
+  for (int t = 0; t < NSTAGE - 1 && t < nt; ++t) stage(t, t);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 2 < nt && NSTAGE >= 4)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+    else if (t + 1 < nt && NSTAGE >= 3)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1) % NSTAGE is free
+    if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+    const char *base = lds + (t % NSTAGE) * NIMG * IMG;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf8 a[C::FM], b[C::FN], al[C::FM], bl[C::FN];
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        b[j] = read_frag<BKC, TB>(base + IMG, wn + 16 * j, s, lane);
+        if (SPLIT == 3) bl[j] = read_frag<BKC, TB>(base + 3 * IMG, wn + 16 * j, s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i) {
+        a[i] = read_frag<AKC, TB>(base, wm + 16 * i, s, lane);
+        if (SPLIT == 3) al[i] = read_frag<AKC, TB>(base + 2 * IMG, wm + 16 * i, s, lane);
+      }
+      if (!AKC || !BKC) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) {
+          if (SPLIT == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  __syncthreads();  // the second product (or the next use of LDS) may restage buffer 0
+}
+
+__device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+// One kernel per operand layout (AKC, BKC): a run-time switch over the four main loops costs ~70
+// VGPRs and spills the 256x256 configuration.  The launcher groups products by layout.
+template <int SPLIT, int TB, bool AKC, bool BKC>
+__global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(GemmGroup g) {
+  using C = Cfg<TB>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const GemmProb &p = g.p[blockIdx.z];
+  const int n = g.n;
+  const int tiles = n / TB;
+  // XCD-aware remap (speed only, bijective): blocks b and b+8 share an XCD and its 4 MiB L2.  The
+  // blocks an XCD runs together are made compact 4 x 8 super-tiles, so per k-step they pull
+  // 4 A-panels + 8 B-panels through that L2 instead of 1 + 32.
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    if ((tiles & 7) == 0) {
+      const int nwg = tiles * tiles;
+      const int lin = (bid & 7) * (nwg >> 3) + (bid >> 3);  // XCD x owns a contiguous run of lin
+      const int st = lin >> 5, local = lin & 31;            // super-tile major order
+      const int st_cols = tiles >> 3;
+      tm = (st / st_cols) * 4 + (local >> 3);
+      tn = (st % st_cols) * 8 + (local & 7);
+    } else {
+      tm = bid / tiles;
+      tn = bid % tiles;
+    }
+  }
+  const int m0 = tm * TB, n0 = tn * TB;
+  const long b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  f32x4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int prod = 0; prod < 2; ++prod) {
+    const uint16_t *Ah = (const uint16_t *)(prod ? p.A2 : p.A);
+    if (!Ah) continue;
+    const long sA = prod ? p.sA2 : p.sA, sB = prod ? p.sB2 : p.sB;
+    BfOperand A{Ah + b * sA, (const uint16_t *)(prod ? p.A2l : p.Al) + b * sA};
+    BfOperand B{(const uint16_t *)(prod ? p.B2 : p.B) + b * sB, (const uint16_t *)(prod ? p.B2l : p.Bl) + b * sB};
+    mainloop<SPLIT, TB, AKC, BKC>(acc, A, B, n, m0, n0, lds, wave, lane);
+  }
+
+  const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
+  float *Cf = p.C ? p.C + b * p.sC : nullptr;
+  uint16_t *Ch = p.Cb ? (uint16_t *)p.Cb + b * p.sC : nullptr;
+  uint16_t *Cl = p.Cbl ? (uint16_t *)p.Cbl + b * p.sC : nullptr;
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) {
+      const int col = n0 + wn + 16 * j + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + 16 * i + (lane >> 4) * 4 + r;
+        const long o = (long)row * n + col;
+        float v = acc[i][j][r];
+        if (Cf) {
+          if (p.beta) v += Cf[o];
+          Cf[o] = v;
+        }
+        if (Ch) {
+          const uint16_t h = f2bf(v);
+          Ch[o] = h;
+          if (Cl) Cl[o] = f2bf(v - bf2f(h));
+        }
+      }
+    }
+}
+
+template <int SPLIT, int TB, bool AKC, bool BKC>
+int launch_one(const GemmGroup &g, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = 128 * 1024;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr_set = true;
+  }
+  const int tiles = g.n / TB;
+  hipLaunchKernelGGL((gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC>), dim3(tiles * tiles, g.batch, g.nprob),
+                     dim3(Cfg<TB>::WAVES * 64), lds, s, g);
+  return check_launch();
+}
+
+template <int SPLIT, int TB>
+int launch_layout(const GemmGroup &g, int code, hipStream_t s) {
+  switch (code) {
+    case 3: return launch_one<SPLIT, TB, true, true>(g, s);
+    case 2: return launch_one<SPLIT, TB, true, false>(g, s);
+    case 1: return launch_one<SPLIT, TB, false, true>(g, s);
+    default: return launch_one<SPLIT, TB, false, false>(g, s);
+  }
+}
+
+// op(A)(m,k) is k-contiguous unless transposed; op(B)(k,c) is k-contiguous only when transposed
+inline int layout_code(int ta, int tb) { return (ta ? 0 : 2) | (tb ? 1 : 0); }
+
+}  // namespace
+
+int launch_gemm_group_bf16(const GemmGroup &g, int split, hipStream_t s) {
+  if (g.nprob < 1 || g.nprob > MAX_GROUP || g.n <= 0 || g.n % 128 || g.batch < 1) return CRW_EINVAL;
+  // pass 0: first products (plus second products of the same layout); pass 1: second products whose
+  // layout differs, accumulated with beta = 1 (needs the fp32 C)
+  for (int pass = 0; pass < 2; ++pass)
+    for (int code = 0; code < 4; ++code) {
+      GemmGroup sub{};
+      sub.n = g.n;
+      sub.batch = g.batch;
+      for (int i = 0; i < g.nprob; ++i) {
+        const GemmProb &p = g.p[i];
+        const int c1 = layout_code(p.ta, p.tb);
+        const bool two = p.A2 != nullptr;
+        const int c2 = two ? layout_code(p.ta2, p.tb2) : c1;
+        if (pass == 0 && c1 == code) {
+          GemmProb q = p;
+          if (two && c2 != c1) {  // second product goes to pass 1; keep the bf16 images for the end
+            if (!p.C) return CRW_EINVAL;
+            q.A2 = q.B2 = q.A2l = q.B2l = nullptr;
+            q.Cb = q.Cbl = nullptr;
+          }
+          sub.p[sub.nprob++] = q;
+        } else if (pass == 1 && two && c2 != c1 && c2 == code) {
+          GemmProb q = p;
+          q.A = p.A2; q.B = p.B2; q.Al = p.A2l; q.Bl = p.B2l;
+          q.sA = p.sA2; q.sB = p.sB2; q.ta = p.ta2; q.tb = p.tb2;
+          q.A2 = q.B2 = q.A2l = q.B2l = nullptr;
+          q.beta = 1;
+          sub.p[sub.nprob++] = q;
+        }
+      }
+      if (!sub.nprob) continue;
+      // 256 x 256 tiles (half the operand bytes per flop) when they still fill the chip
+      const bool big = split != 3 && (g.n % 256 == 0) &&
+                       ((long)(g.n / 256) * (g.n / 256) * sub.batch * sub.nprob >= 256);
+      int st;
+      if (split == 3) st = launch_layout<3, 128>(sub, code, s);
+      else st = big ? launch_layout<1, 256>(sub, code, s) : launch_layout<1, 128>(sub, code, s);
+      if (st != CRW_OK) return st;
+    }
+  return CRW_OK;
+}
+
+// fp32 [count] -> bf16 hi (and lo) images
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, long count,
+                                                         uint16_t *__restrict__ hi, uint16_t *__restrict__ lo) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    const uint16_t h = f2bf(v);
+    hi[i] = h;
+    if (lo) lo[i] = f2bf(v - bf2f(h));
+  }
+}
+
+int launch_split_bf16(const float *x, long count, void *hi, void *lo, hipStream_t s) {
+  long blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, count, (uint16_t *)hi,
+                     (uint16_t *)lo);
+  return check_launch();
+}
+
+}  // namespace crw
+
+// A, B fp32 [batch][n][n] are converted to bf16 (hi[,lo]) images in `ws` (crw_gemm_bf16_ws_bytes),
+// then C = op(A) op(B) (+C) with bf16 MFMA.  split = 1 (plain bf16) or 3 (hi/lo, fp32-grade).
+extern "C" size_t crw_gemm_bf16_ws_bytes(int n, int batch, int split) {
+  if (n < 1 || batch < 1) return 0;
+  return (size_t)n * n * batch * 2 * 2 * (split == 3 ? 2 : 1);
+}
+
+extern "C" int crw_gemm_bf16(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
+                             int beta, int split, void *ws, size_t ws_bytes, int convert, crw_stream_t stream) {
+  crw::clear_stale_error();
+  if (!A || !B || !C || !ws || (split != 1 && split != 3)) return CRW_EINVAL;
+  if (n < 128 || n % 128) return CRW_EINVAL;
+  if (ws_bytes < crw_gemm_bf16_ws_bytes(n, batch, split)) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const long cnt = (long)n * n * batch;
+  uint16_t *Ah = (uint16_t *)ws, *Bh = Ah + cnt, *Al = nullptr, *Bl = nullptr;
+  if (split == 3) { Al = Bh + cnt; Bl = Al + cnt; }
+  if (convert) {
+    CRW_TRY(crw::launch_split_bf16(A, cnt, Ah, Al, s));
+    CRW_TRY(crw::launch_split_bf16(B, cnt, Bh, Bl, s));
+  }
+  crw::GemmGroup g{};
+  g.nprob = 1; g.n = n; g.batch = batch;
+  crw::GemmProb &p = g.p[0];
+  p.A = Ah; p.Al = Al; p.B = Bh; p.Bl = Bl; p.C = C;
+  p.sA = p.sB = p.sC = (long)n * n;
+  p.ta = transA; p.tb = transB; p.beta = beta;
+  return crw::launch_gemm_group_bf16(g, split, s);
+}

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void identity_kernel(float *__restrict__ R, ui
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < per; idx += (long)gridDim.x * 256) {
     const int i = idx / Np, j = idx % Np;
     const float v = (i == j && i < N) ? 1.f : 0.f;
-    R[mat * per + idx] = v;
+    if (R) R[mat * per + idx] = v;
     if (Rb) Rb[mat * per + idx] = f2bf(v);
   }
 }

@@ -46,12 +46,19 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restr
   for (int c = lane; c < C; c += 64) de[row * C + c] = (dehat[row * C + c] - ehat[row * C + c] * dot) / d;
 }
 
+// fp32 plane + optional bf16 hi / lo images of one family of [Np][Np] matrices
+struct Mat {
+  float *f = nullptr;
+  uint16_t *h = nullptr, *l = nullptr;
+};
 struct WalkState {
-  float *F, *Gt, *Lt, *R, *At, *lse, *terms, *stats;
+  Mat F, Gt, Lt, R, At;
+  float *lse, *terms, *stats;
   size_t bytes;
 };
 struct WalkScratch {
-  float *dAt, *dF, *dGt, *dLt, *dR, *stats;
+  Mat dAt, dF, dGt, dLt, dR;
+  float *stats;
   size_t bytes;
 };
 
@@ -62,15 +69,28 @@ T *carve(char *&p, size_t count) {
   return r;
 }
 
-WalkState layout_state(void *base, int B, int T, int N) {
-  const size_t Np = padded_nodes(N), K = T - 2, nA = (size_t)B * (T - 1), M = Np * Np;
+// which planes a family needs: fp32 chain -> fp32 only; bf16 chains -> per family
+Mat carve_mat(char *&p, size_t count, int chain, bool want_f32_in_bf16_mode, bool want_img_in_bf16_mode = true) {
+  Mat m;
+  if (chain == CRW_CHAIN_F32 || want_f32_in_bf16_mode) m.f = carve<float>(p, count);
+  if (chain != CRW_CHAIN_F32 && want_img_in_bf16_mode) {
+    m.h = carve<uint16_t>(p, count);
+    if (chain == CRW_CHAIN_BF16X3) m.l = carve<uint16_t>(p, count);
+  }
+  return m;
+}
+
+int chain_padded_nodes(int N, int chain) { return chain == CRW_CHAIN_F32 ? padded_nodes(N) : round_up(N, 128); }
+
+WalkState layout_state(void *base, int B, int T, int N, int chain) {
+  const size_t Np = chain_padded_nodes(N, chain), K = T - 2, nA = (size_t)B * (T - 1), M = Np * Np;
   char *p = static_cast<char *>(base);
   WalkState s;
-  s.F = carve<float>(p, nA * M);
-  s.Gt = carve<float>(p, nA * M);
-  s.Lt = carve<float>(p, K * B * M);
-  s.R = carve<float>(p, K * B * M);
-  s.At = carve<float>(p, K * B * M);
+  s.F = carve_mat(p, nA * M, chain, true);    // fp32 kept for the softmax backward
+  s.Gt = carve_mat(p, nA * M, chain, true);
+  s.Lt = carve_mat(p, K * B * M, chain, false);  // bf16 chains: operands only
+  s.R = carve_mat(p, K * B * M, chain, false);
+  s.At = carve_mat(p, K * B * M, chain, true, false);  // loss needs fp32; never a GEMM operand
   s.lse = carve<float>(p, K * B * Np);
   s.terms = carve<float>(p, K * B * Np);
   s.stats = carve<float>(p, 4 * nA * Np);
@@ -78,21 +98,64 @@ WalkState layout_state(void *base, int B, int T, int N) {
   return s;
 }
 
-WalkScratch layout_scratch(void *base, int B, int T, int N) {
-  const size_t Np = padded_nodes(N), K = T - 2, nA = (size_t)B * (T - 1), M = Np * Np;
+WalkScratch layout_scratch(void *base, int B, int T, int N, int chain) {
+  const size_t Np = chain_padded_nodes(N, chain), K = T - 2, nA = (size_t)B * (T - 1), M = Np * Np;
   char *p = static_cast<char *>(base);
   WalkScratch s;
-  s.dAt = carve<float>(p, K * B * M);
-  s.dF = carve<float>(p, nA * M);
-  s.dGt = carve<float>(p, nA * M);
-  s.dLt = carve<float>(p, 2 * (size_t)B * M);
-  s.dR = carve<float>(p, 2 * (size_t)B * M);
+  s.dAt = carve_mat(p, K * B * M, chain, true);
+  s.dF = carve_mat(p, nA * M, chain, true, false);
+  s.dGt = carve_mat(p, nA * M, chain, true, false);
+  s.dLt = carve_mat(p, 2 * (size_t)B * M, chain, true);  // fp32 needed: two-term accumulation across launches
+  s.dR = carve_mat(p, 2 * (size_t)B * M, chain, true);
   s.stats = carve<float>(p, 2 * nA * Np);
   s.bytes = p - static_cast<char *>(base);
   return s;
 }
 
 bool bad_shape(int B, int T, int N) { return B < 1 || T < 2 || N < 1 || N > 16384; }
+bool bad_chain(int chain) { return chain != CRW_CHAIN_F32 && chain != CRW_CHAIN_BF16 && chain != CRW_CHAIN_BF16X3; }
+
+// operand / result descriptors for either arithmetic
+struct Opnd {
+  const Mat *m;
+  long off;     // element offset of batch item 0
+  long stride;  // batch stride
+};
+void set_a(GemmProb &p, int chain, Opnd o, int t) {
+  if (chain == CRW_CHAIN_F32) p.A = o.m->f + o.off;
+  else { p.A = o.m->h + o.off; p.Al = o.m->l ? o.m->l + o.off : nullptr; }
+  p.sA = o.stride; p.ta = t;
+}
+void set_b(GemmProb &p, int chain, Opnd o, int t) {
+  if (chain == CRW_CHAIN_F32) p.B = o.m->f + o.off;
+  else { p.B = o.m->h + o.off; p.Bl = o.m->l ? o.m->l + o.off : nullptr; }
+  p.sB = o.stride; p.tb = t;
+}
+void set_a2(GemmProb &p, int chain, Opnd o, int t) {
+  if (chain == CRW_CHAIN_F32) p.A2 = o.m->f + o.off;
+  else { p.A2 = o.m->h + o.off; p.A2l = o.m->l ? o.m->l + o.off : nullptr; }
+  p.sA2 = o.stride; p.ta2 = t;
+}
+void set_b2(GemmProb &p, int chain, Opnd o, int t) {
+  if (chain == CRW_CHAIN_F32) p.B2 = o.m->f + o.off;
+  else { p.B2 = o.m->h + o.off; p.B2l = o.m->l ? o.m->l + o.off : nullptr; }
+  p.sB2 = o.stride; p.tb2 = t;
+}
+void set_c(GemmProb &p, Opnd o) {
+  p.C = o.m->f ? o.m->f + o.off : nullptr;
+  p.Cb = o.m->h ? o.m->h + o.off : nullptr;
+  p.Cbl = o.m->l ? o.m->l + o.off : nullptr;
+  p.sC = o.stride;
+}
+int launch_group(const GemmGroup &g, int chain, hipStream_t s) {
+  if (chain == CRW_CHAIN_F32) return launch_gemm_group_f32(g, s);
+  return launch_gemm_group_bf16(g, chain == CRW_CHAIN_BF16X3 ? 3 : 1, s);
+}
+// fp32 plane -> bf16 images of the same family (no-op for the fp32 chain)
+int make_images(const Mat &m, long count, hipStream_t s) {
+  if (!m.h) return CRW_OK;
+  return launch_split_bf16(m.f, count, m.h, m.l, s);
+}
 
 }  // namespace
 }  // namespace crw
@@ -101,18 +164,18 @@ using namespace crw;
 
 extern "C" {
 
-int crw_abi_version(void) { return 1; }
+int crw_abi_version(void) { return 2; }
 const char *crw_build_arch(void) { return "gfx950"; }
 int crw_last_hip_error(void) { return g_last_hip_error; }
-int crw_padded_nodes(int N) { return N < 1 ? 0 : padded_nodes(N); }
+int crw_padded_nodes(int N, int chain) { return (N < 1 || bad_chain(chain)) ? 0 : chain_padded_nodes(N, chain); }
 
-size_t crw_walk_state_bytes(int B, int T, int N) {
-  if (bad_shape(B, T, N) || T < 3) return 256;
-  return layout_state(nullptr, B, T, N).bytes;
+size_t crw_walk_state_bytes(int B, int T, int N, int chain) {
+  if (bad_shape(B, T, N) || bad_chain(chain) || T < 3) return 256;
+  return layout_state(nullptr, B, T, N, chain).bytes;
 }
-size_t crw_walk_scratch_bytes(int B, int T, int N) {
-  if (bad_shape(B, T, N) || T < 3) return 256;
-  return layout_scratch(nullptr, B, T, N).bytes;
+size_t crw_walk_scratch_bytes(int B, int T, int N, int chain) {
+  if (bad_shape(B, T, N) || bad_chain(chain) || T < 3) return 256;
+  return layout_scratch(nullptr, B, T, N, chain).bytes;
 }
 
 int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, crw_stream_t stream) {
@@ -147,54 +210,61 @@ int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau, fl
 int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, size_t state_bytes, float *At_out,
                  float *loss, crw_stream_t stream) {
   crw::clear_stale_error();
-  if (!A || !loss || bad_shape(B, T, N)) return CRW_EINVAL;
-  if (chain != CRW_CHAIN_F32) return CRW_EINVAL;
+  if (!A || !loss || bad_shape(B, T, N) || bad_chain(chain)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (T < 3) {  // no cycle: the reference returns 0/N
     if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return CRW_EHIP;
     return CRW_OK;
   }
   if (!state) return CRW_EINVAL;
-  WalkState st = layout_state(state, B, T, N);
+  WalkState st = layout_state(state, B, T, N, chain);
   if (state_bytes < st.bytes) return CRW_EWORKSPACE;
-  const int Np = padded_nodes(N), K = T - 2, nA = B * (T - 1);
-  const long M = (long)Np * Np;
+  const int Np = chain_padded_nodes(N, chain), K = T - 2, nA = B * (T - 1);
+  const long M = (long)Np * Np, SA = (long)(T - 1) * M;  // SA: batch stride inside F / Gt
 
-  CRW_TRY(launch_softmax_fwd(A, nA, N, Np, st.F, st.Gt, nullptr, nullptr, st.stats, s));
-  CRW_TRY(launch_copy_f32(st.Lt, st.Gt, M, (long)(T - 1) * M, M, B, s));  // Lt_1 = Gt_0
-  CRW_TRY(launch_identity(st.R, nullptr, B, Np, N, s));                   // R_1 = I
+  CRW_TRY(launch_softmax_fwd(A, nA, N, Np, st.F.f, st.Gt.f, nullptr, nullptr, st.stats, s));
+  CRW_TRY(make_images(st.F, (long)nA * M, s));
+  CRW_TRY(make_images(st.Gt, (long)nA * M, s));
+  if (chain == CRW_CHAIN_F32) {
+    CRW_TRY(launch_copy_f32(st.Lt.f, st.Gt.f, M, SA, M, B, s));  // Lt_1 = Gt_0
+    CRW_TRY(launch_identity(st.R.f, nullptr, B, Np, N, s));      // R_1 = I
+  } else {  // the same on the bf16 images (two bf16 per float lane of the copy kernel)
+    CRW_TRY(launch_copy_f32((float *)st.Lt.h, (const float *)st.Gt.h, M / 2, SA / 2, M / 2, B, s));
+    if (st.Lt.l) CRW_TRY(launch_copy_f32((float *)st.Lt.l, (const float *)st.Gt.l, M / 2, SA / 2, M / 2, B, s));
+    CRW_TRY(launch_identity(nullptr, st.R.h, B, Np, N, s));
+    if (st.R.l && hipMemsetAsync(st.R.l, 0, sizeof(uint16_t) * B * M, s) != hipSuccess) return CRW_EHIP;
+  }
 
   for (int k = 1; k <= K; ++k) {
     GemmGroup g{};
     g.n = Np; g.batch = B;
-    float *Lt_k = st.Lt + (long)(k - 1) * B * M, *R_k = st.R + (long)(k - 1) * B * M;
-    GemmProb &p0 = g.p[g.nprob++];  // At_k = Lt_k^T R_k
-    p0.A = Lt_k; p0.ta = 1; p0.sA = M;
-    p0.B = R_k; p0.sB = M;
-    p0.C = st.At + (long)(k - 1) * B * M; p0.sC = M;
+    const long ok = (long)(k - 1) * B * M;  // offset of Lt_k / R_k / At_k
+    GemmProb &p0 = g.p[g.nprob++];          // At_k = Lt_k^T R_k
+    set_a(p0, chain, {&st.Lt, ok, M}, 1);
+    set_b(p0, chain, {&st.R, ok, M}, 0);
+    set_c(p0, {&st.At, ok, M});
     if (k < K) {
       GemmProb &p1 = g.p[g.nprob++];  // Lt_{k+1} = Gt_k Lt_k
-      p1.A = st.Gt + (long)k * M; p1.sA = (long)(T - 1) * M;
-      p1.B = Lt_k; p1.sB = M;
-      p1.C = Lt_k + (long)B * M; p1.sC = M;
+      set_a(p1, chain, {&st.Gt, (long)k * M, SA}, 0);
+      set_b(p1, chain, {&st.Lt, ok, M}, 0);
+      set_c(p1, {&st.Lt, ok + (long)B * M, M});
       GemmProb &p2 = g.p[g.nprob++];  // R_{k+1} = F_k R_k
-      p2.A = st.F + (long)k * M; p2.sA = (long)(T - 1) * M;
-      p2.B = R_k; p2.sB = M;
-      p2.C = R_k + (long)B * M; p2.sC = M;
+      set_a(p2, chain, {&st.F, (long)k * M, SA}, 0);
+      set_b(p2, chain, {&st.R, ok, M}, 0);
+      set_c(p2, {&st.R, ok + (long)B * M, M});
     }
-    CRW_TRY(launch_gemm_group_f32(g, s));
+    CRW_TRY(launch_group(g, chain, s));
   }
-  CRW_TRY(launch_loss_rows(st.At, K * B, N, Np, st.lse, st.terms, s));
+  CRW_TRY(launch_loss_rows(st.At.f, K * B, N, Np, st.lse, st.terms, s));
   CRW_TRY(launch_loss_reduce(st.terms, (long)K * B * Np, 1.0f / ((float)B * (float)N * (float)N), loss, s));
-  if (At_out) CRW_TRY(launch_unpad_At(st.At, K, B, N, Np, At_out, s));
+  if (At_out) CRW_TRY(launch_unpad_At(st.At.f, K, B, N, Np, At_out, s));
   return CRW_OK;
 }
 
 int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state, size_t state_bytes, void *scratch,
                  size_t scratch_bytes, float *dA, crw_stream_t stream) {
   crw::clear_stale_error();
-  if (!gloss || !dA || bad_shape(B, T, N)) return CRW_EINVAL;
-  if (chain != CRW_CHAIN_F32) return CRW_EINVAL;
+  if (!gloss || !dA || bad_shape(B, T, N) || bad_chain(chain)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long NN = (long)N * N;
   if (T < 3) {
@@ -202,45 +272,50 @@ int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state
     return CRW_OK;
   }
   if (!state || !scratch) return CRW_EINVAL;
-  WalkState st = layout_state(state, B, T, N);
-  WalkScratch sc = layout_scratch(scratch, B, T, N);
+  WalkState st = layout_state(state, B, T, N, chain);
+  WalkScratch sc = layout_scratch(scratch, B, T, N, chain);
   if (state_bytes < st.bytes || scratch_bytes < sc.bytes) return CRW_EWORKSPACE;
-  const int Np = padded_nodes(N), K = T - 2, nA = B * (T - 1);
-  const long M = (long)Np * Np;
+  const int Np = chain_padded_nodes(N, chain), K = T - 2, nA = B * (T - 1);
+  const long M = (long)Np * Np, SA = (long)(T - 1) * M;
 
   const float coef = 1.0f / ((float)N * (float)B * (float)N);
-  CRW_TRY(launch_dAt(st.At, st.lse, gloss, coef, K * B, N, Np, sc.dAt, nullptr, s));
-  if (hipMemsetAsync(sc.dF, 0, sizeof(float) * nA * M, s) != hipSuccess) return CRW_EHIP;
-  if (hipMemsetAsync(sc.dGt, 0, sizeof(float) * nA * M, s) != hipSuccess) return CRW_EHIP;
+  CRW_TRY(launch_dAt(st.At.f, st.lse, gloss, coef, K * B, N, Np, sc.dAt.f, nullptr, s));
+  CRW_TRY(make_images(sc.dAt, (long)K * B * M, s));
+  if (hipMemsetAsync(sc.dF.f, 0, sizeof(float) * nA * M, s) != hipSuccess) return CRW_EHIP;
+  if (hipMemsetAsync(sc.dGt.f, 0, sizeof(float) * nA * M, s) != hipSuccess) return CRW_EHIP;
 
   for (int k = K; k >= 1; --k) {
     GemmGroup g{};
     g.n = Np; g.batch = B;
-    const float *Lt_k = st.Lt + (long)(k - 1) * B * M, *R_k = st.R + (long)(k - 1) * B * M;
-    const float *dAt_k = sc.dAt + (long)(k - 1) * B * M;
-    float *dLt_cur = sc.dLt + (long)(k & 1) * B * M, *dLt_nxt = sc.dLt + (long)((k + 1) & 1) * B * M;
-    float *dR_cur = sc.dR + (long)(k & 1) * B * M, *dR_nxt = sc.dR + (long)((k + 1) & 1) * B * M;
+    const long ok = (long)(k - 1) * B * M;
+    const long cur = (long)(k & 1) * B * M, nxt = (long)((k + 1) & 1) * B * M;
     GemmProb &p0 = g.p[g.nprob++];  // dLt_k = R_k dAt_k^T (+ Gt_k^T dLt_{k+1})
-    p0.A = R_k; p0.sA = M; p0.B = dAt_k; p0.sB = M; p0.tb = 1;
-    p0.C = dLt_cur; p0.sC = M;
+    set_a(p0, chain, {&st.R, ok, M}, 0);
+    set_b(p0, chain, {&sc.dAt, ok, M}, 1);
+    set_c(p0, {&sc.dLt, cur, M});
     GemmProb &p1 = g.p[g.nprob++];  // dR_k = Lt_k dAt_k (+ F_k^T dR_{k+1})
-    p1.A = Lt_k; p1.sA = M; p1.B = dAt_k; p1.sB = M;
-    p1.C = dR_cur; p1.sC = M;
+    set_a(p1, chain, {&st.Lt, ok, M}, 0);
+    set_b(p1, chain, {&sc.dAt, ok, M}, 0);
+    set_c(p1, {&sc.dR, cur, M});
     if (k < K) {
-      p0.A2 = st.Gt + (long)k * M; p0.sA2 = (long)(T - 1) * M; p0.ta2 = 1; p0.B2 = dLt_nxt; p0.sB2 = M;
-      p1.A2 = st.F + (long)k * M; p1.sA2 = (long)(T - 1) * M; p1.ta2 = 1; p1.B2 = dR_nxt; p1.sB2 = M;
+      set_a2(p0, chain, {&st.Gt, (long)k * M, SA}, 1);
+      set_b2(p0, chain, {&sc.dLt, nxt, M}, 0);
+      set_a2(p1, chain, {&st.F, (long)k * M, SA}, 1);
+      set_b2(p1, chain, {&sc.dR, nxt, M}, 0);
       GemmProb &p2 = g.p[g.nprob++];  // dGt_k = dLt_{k+1} Lt_k^T
-      p2.A = dLt_nxt; p2.sA = M; p2.B = Lt_k; p2.sB = M; p2.tb = 1;
-      p2.C = sc.dGt + (long)k * M; p2.sC = (long)(T - 1) * M;
+      set_a(p2, chain, {&sc.dLt, nxt, M}, 0);
+      set_b(p2, chain, {&st.Lt, ok, M}, 1);
+      set_c(p2, {&sc.dGt, (long)k * M, SA});
       GemmProb &p3 = g.p[g.nprob++];  // dF_k = dR_{k+1} R_k^T
-      p3.A = dR_nxt; p3.sA = M; p3.B = R_k; p3.sB = M; p3.tb = 1;
-      p3.C = sc.dF + (long)k * M; p3.sC = (long)(T - 1) * M;
+      set_a(p3, chain, {&sc.dR, nxt, M}, 0);
+      set_b(p3, chain, {&st.R, ok, M}, 1);
+      set_c(p3, {&sc.dF, (long)k * M, SA});
     }
-    CRW_TRY(launch_gemm_group_f32(g, s));
+    CRW_TRY(launch_group(g, chain, s));
   }
   // Lt_1 = Gt_0  ->  dGt_0 = dLt_1
-  CRW_TRY(launch_copy_f32(sc.dGt, sc.dLt + (long)(1 & 1) * B * M, (long)(T - 1) * M, M, M, B, s));
-  CRW_TRY(launch_softmax_bwd(st.F, st.Gt, sc.dF, sc.dGt, nA, N, Np, sc.stats, dA, s));
+  CRW_TRY(launch_copy_f32(sc.dGt.f, sc.dLt.f + (long)(1 & 1) * B * M, SA, M, M, B, s));
+  CRW_TRY(launch_softmax_bwd(st.F.f, st.Gt.f, sc.dF.f, sc.dGt.f, nA, N, Np, sc.stats, dA, s));
   return CRW_OK;
 }
 

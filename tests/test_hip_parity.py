@@ -40,6 +40,30 @@ def test_gemm_f32_matches_torch(hip, n, batch, ta, tb):
     torch.testing.assert_close(acc.double(), ref + C0.double(), rtol=1e-5, atol=1e-5 * n ** 0.5)
 
 
+@pytest.mark.parametrize("n,batch", [(128, 2), (256, 1), (384, 2), (1024, 16)])  # last: 256x256-tile kernel
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("split", [1, 3])
+def test_gemm_bf16_matches_torch(hip, n, batch, ta, tb, split):
+    g = torch.Generator().manual_seed(n + 7 * ta + 3 * tb + split)
+    # asymmetric, non-negative-biased operands (probability-like) + a signed part
+    A = (torch.rand(batch, n, n, generator=g) + 0.1 * torch.randn(batch, n, n, generator=g)).cuda()
+    B = (torch.rand(batch, n, n, generator=g) * torch.linspace(0.5, 1.5, n)[None, None, :]).cuda()
+    if n >= 1024 and split == 3:
+        pytest.skip('split-3 always uses the 128x128 kernel (covered by the smaller sizes)')
+    opA = lambda X: X.transpose(1, 2) if ta else X
+    opB = lambda X: X.transpose(1, 2) if tb else X
+    out, ws = hip.gemm_bf16(A, B, transA=ta, transB=tb, split=split)
+    if split == 1:  # exact products of the bf16-rounded operands, fp32 accumulation
+        ref = opA(A.bfloat16().double()) @ opB(B.bfloat16().double())
+        torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=1e-4)
+    else:
+        ref = opA(A.double()) @ opB(B.double())
+        torch.testing.assert_close(out.double(), ref, rtol=3e-5, atol=3e-5 * n ** 0.5)
+    C0 = torch.randn(batch, n, n, generator=g).cuda()
+    acc, _ = hip.gemm_bf16(A, B, C0.clone(), transA=ta, transB=tb, beta=True, split=split, ws=ws, convert=False)
+    torch.testing.assert_close(acc, out + C0, rtol=1e-6, atol=1e-4)
+
+
 @pytest.mark.parametrize("name", WALK_CASES)
 def test_training_path_matches_reference(hip, name):
     import model as crw_model
@@ -56,6 +80,29 @@ def test_training_path_matches_reference(hip, name):
     loss2.backward()
     scale = np.abs(g["demb"]).max()
     np.testing.assert_allclose(emb.grad.cpu().numpy(), g["demb"], rtol=2e-3, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize("name", ["walk_cfg1_B2T8N7", "walk_cfg2_B1T16N63", "walk_N70_B2T6", "walk_noise_B2T8N7_tau0p1"])
+@pytest.mark.parametrize("chain", [1, 2])
+def test_bf16_chain_modes_match_reference(hip, name, chain):
+    """CRW_CHAIN_BF16X3 (hi/lo operand pairs) keeps the fp32 parity bar; CRW_CHAIN_BF16 (plain bf16
+    probabilities) is the throughput mode and is held to a looser, stated tolerance."""
+    import model as crw_model
+    g = load_golden(name)
+    tau = float(g["tau"])
+    emb = dev(g["emb"]).requires_grad_(True)
+    A = crw_model.affinity(emb, tau)
+    loss, state, At = hip.walk_fwd(A.detach().contiguous(), chain=chain, want_At=True)
+    if chain == 2:
+        np.testing.assert_allclose(At.cpu().numpy(), g["At"], rtol=2e-4, atol=2e-6)
+        assert abs(loss.item() - float(g["loss"])) <= 1e-4
+    else:
+        np.testing.assert_allclose(At.cpu().numpy(), g["At"], rtol=3e-2, atol=2e-3)
+        assert abs(loss.item() - float(g["loss"])) <= 5e-3
+    crw_model.walk_loss(A, chain).backward()
+    scale = np.abs(g["demb"]).max()
+    tol = 2e-3 if chain == 2 else 6e-2
+    np.testing.assert_allclose(emb.grad.cpu().numpy(), g["demb"], rtol=10 * tol, atol=tol * scale)
 
 
 def test_no_cycle_T2(hip):

@@ -25,13 +25,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in crw_hip.h but not exported"
     assert declared == set(crw_hip.SIGNATURES), declared ^ set(crw_hip.SIGNATURES)
     lib = crw_hip.lib()
-    assert lib.crw_abi_version() == 1 and lib.crw_build_arch() == b"gfx950"
+    assert lib.crw_abi_version() == 2 and lib.crw_build_arch() == b"gfx950"
     # pure host-side geometry queries
-    assert [lib.crw_padded_nodes(n) for n in (1, 7, 63, 64, 65, 128, 129, 497, 1024, 1025, 4096)] == \
+    assert [lib.crw_padded_nodes(n, 0) for n in (1, 7, 63, 64, 65, 128, 129, 497, 1024, 1025, 4096)] == \
         [32, 32, 64, 64, 96, 128, 192, 512, 1024, 1152, 4096]
-    assert lib.crw_walk_state_bytes(1, 2, 8) == 256
-    s1, s2 = lib.crw_walk_state_bytes(1, 32, 63), lib.crw_walk_state_bytes(2, 32, 63)
+    assert [lib.crw_padded_nodes(n, 1) for n in (7, 63, 128, 129, 4096)] == [128, 128, 128, 256, 4096]
+    assert lib.crw_walk_state_bytes(1, 2, 8, 0) == 256
+    s1, s2 = lib.crw_walk_state_bytes(1, 32, 63, 0), lib.crw_walk_state_bytes(2, 32, 63, 0)
     assert 0 < s1 < s2 <= 2 * s1
+    assert lib.crw_walk_state_bytes(1, 8, 200, 2) > lib.crw_walk_state_bytes(1, 8, 200, 1) > 0
 
 
 def test_cpu_tensors_are_refused():
