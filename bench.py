@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain"],
+                    help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
+                         "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder")
+    ap.add_argument("--nodes", type=int, default=4096, help="N of the chain workload")
+    ap.add_argument("--walk", type=int, default=32, help="T (frames) of the chain workload")
     return ap.parse_args()
 
 
@@ -131,8 +136,55 @@ def cpu_baseline(budget_s):
                       f"torch {torch.__version__} CPU ops"}
 
 
+def bench_chain(args):
+    """Shape family K: features [1, T, N, 128] straight into affinity + walk (fwd+bwd) for each chain
+    arithmetic; flops counted = MFMA products actually executed by the prefix-form chain."""
+    import crw_hip
+    import model as crw_model
+    T, N, C = args.walk, args.nodes, 128
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(1, 1, N, C, generator=g)
+    emb0 = (base + 0.5 * torch.randn(1, T, N, C, generator=g)).cuda()
+    nprod = 9 * (T - 3) + 3
+    res, ref_loss = {}, None
+    for name, chain, mult in (("f32", crw_hip.CHAIN_F32, 1), ("bf16x3", crw_hip.CHAIN_BF16X3, 3),
+                              ("bf16", crw_hip.CHAIN_BF16, 1)):
+        Np = crw_hip.padded_nodes(N, chain)
+
+        def step():
+            emb = emb0.clone().requires_grad_(True)
+            A = crw_model.affinity(emb, 0.05)
+            loss = crw_model.walk_loss(A, chain)
+            loss.backward()
+            return loss
+
+        for _ in range(max(1, args.warmup)):
+            loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        if ref_loss is None:
+            ref_loss = loss.item()
+        flops = 2.0 * Np ** 3 * nprod * mult
+        peak = PEAK_TFLOPS["f32"] if chain == crw_hip.CHAIN_F32 else PEAK_TFLOPS["bf16"]
+        res[name] = {"ms_per_step": dt * 1e3, "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
+                     "frac": flops / dt / 1e12 / peak, "bound": "mfma", "loss": loss.item(),
+                     "loss_minus_f32": loss.item() - ref_loss, "products": nprod, "n_padded": Np,
+                     "note": "whole affinity+softmax+chain+loss fwd+bwd wall time; flops = chain MFMA flops executed"}
+    print(json.dumps({"metric": "chain fwd+bwd at kernel-only stress shape K", "workload": f"[B,T,N,C]=[1,{T},{N},{C}]",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "data": "synthetic", "modes": res}),
+          flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "chain":
+        import crw_hip
+        crw_hip.lib()
+        return bench_chain(args)
     import dist as crw_dist
     rank, world, local = crw_dist.init_from_env("nccl")
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"

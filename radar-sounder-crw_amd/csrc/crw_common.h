@@ -108,10 +108,15 @@ struct EdgeGemm {
 int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s);
 
 // softmax.hip --------------------------------------------------------------------------------
-int launch_softmax_fwd(const float *A, int nmat, int N, int Np, float *F, float *Gt, void *Fb, void *Gtb,
-                       float *stats /* 4*nmat*Np */, hipStream_t s);
-int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const float *dGt, int nmat, int N,
-                       int Np, float *stats /* 2*nmat*Np */, float *dA, hipStream_t s);
+// A / dA are the caller's [B][T-1][N][N]; F, Gt, dF, dGt and the stats are internal [T-1][B][Np][Np]
+int launch_softmax_fwd(const float *A, int B, int Tm1, int N, int Np, float *F, float *Gt, void *Fb, void *Gtb,
+                       float *stats /* 4*B*Tm1*Np */, hipStream_t s);
+int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const float *dGt, int B, int Tm1, int N,
+                       int Np, float *stats /* 2*B*Tm1*Np */, float *dA, hipStream_t s);
+// persistent small-n chain (chain_small.hip): X_{k+1} = P_k X_k  /  Y_k += P_k^T Y_{k+1}
+int launch_chain_small_fwd(const float *Gt, const float *F, float *Lt, float *R, int B, int K, int n, hipStream_t s);
+int launch_chain_small_bwd(const float *Gt, const float *F, float *dLt, float *dR, int B, int K, int n,
+                           hipStream_t s);
 int launch_identity(float *R, void *Rb, int batch, int Np, int N, hipStream_t s);
 int launch_copy_f32(float *dst, const float *src, long dst_bs, long src_bs, long n_per_batch, int batch,
                     hipStream_t s);

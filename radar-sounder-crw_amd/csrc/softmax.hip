@@ -14,13 +14,13 @@ __device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (
 
 // ---- forward statistics -------------------------------------------------------------------
 // one wave per row: rmax[n], rsum[n]
-__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ A, int N, int Np,
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ A, int B, int Tm1, int N, int Np,
                                                         float *__restrict__ rmax, float *__restrict__ rsum) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
-  const long mat = blockIdx.y;
+  const long mat = blockIdx.y, amat = (mat % B) * Tm1 + mat / B;  // internal [j][b]  <->  caller's [b][j]
   if (row >= N) return;
-  const float *a = A + mat * N * N + (long)row * N;
+  const float *a = A + amat * N * N + (long)row * N;
   float m = -INFINITY;
   for (int c = lane; c < N; c += 64) m = fmaxf(m, a[c]);
   m = wave_max(m);
@@ -34,13 +34,13 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 }
 
 // one lane per column (64 columns per block), the 4 waves split the rows: cmax[m], csum[m]
-__global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ A, int N, int Np,
+__global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ A, int B, int Tm1, int N, int Np,
                                                         float *__restrict__ cmax, float *__restrict__ csum) {
   __shared__ float sm[4][64], ss[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
-  const long mat = blockIdx.y;
-  const float *a = A + mat * N * N;
+  const long mat = blockIdx.y, amat = (mat % B) * Tm1 + mat / B;
+  const float *a = A + amat * N * N;
   float m = -INFINITY;
   if (col < N)
     for (int r = wave; r < N; r += 4) m = fmaxf(m, a[(long)r * N + col]);
@@ -59,20 +59,20 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
 }
 
 // elementwise: F, Gt padded (+ optional bf16 shadows)
-__global__ __launch_bounds__(256) void softmax_write_kernel(const float *__restrict__ A, int N, int Np,
+__global__ __launch_bounds__(256) void softmax_write_kernel(const float *__restrict__ A, int B, int Tm1, int N, int Np,
                                                             const float *__restrict__ rmax,
                                                             const float *__restrict__ rsum,
                                                             const float *__restrict__ cmax,
                                                             const float *__restrict__ csum, float *__restrict__ F,
                                                             float *__restrict__ Gt, uint16_t *__restrict__ Fb,
                                                             uint16_t *__restrict__ Gtb) {
-  const long mat = blockIdx.y;
+  const long mat = blockIdx.y, amat = (mat % B) * Tm1 + mat / B;
   const long per = (long)Np * Np;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < per; idx += (long)gridDim.x * 256) {
     const int n = idx / Np, m = idx % Np;
     float f = 0.f, g = 0.f;
     if (n < N && m < N) {
-      const float a = A[mat * N * N + (long)n * N + m];
+      const float a = A[amat * N * N + (long)n * N + m];
       f = expf(a - rmax[mat * Np + n]) / rsum[mat * Np + n];
       g = expf(a - cmax[mat * Np + m]) / csum[mat * Np + m];
     }
@@ -122,14 +122,14 @@ __global__ __launch_bounds__(256) void softmax_bwd_write_kernel(const float *__r
                                                                 const float *__restrict__ dF,
                                                                 const float *__restrict__ dGt,
                                                                 const float *__restrict__ rdot,
-                                                                const float *__restrict__ cdot, int N, int Np,
-                                                                float *__restrict__ dA) {
-  const long mat = blockIdx.y;
+                                                                const float *__restrict__ cdot, int B, int Tm1,
+                                                                int N, int Np, float *__restrict__ dA) {
+  const long mat = blockIdx.y, amat = (mat % B) * Tm1 + mat / B;
   const long per = (long)N * N;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < per; idx += (long)gridDim.x * 256) {
     const int n = idx / N, m = idx % N;
     const long o = mat * Np * Np + (long)n * Np + m;
-    dA[mat * per + idx] = F[o] * (dF[o] - rdot[mat * Np + n]) + Gt[o] * (dGt[o] - cdot[mat * Np + m]);
+    dA[amat * per + idx] = F[o] * (dF[o] - rdot[mat * Np + n]) + Gt[o] * (dGt[o] - cdot[mat * Np + m]);
   }
 }
 
@@ -231,23 +231,25 @@ inline int ew_blocks(long n) {
 
 }  // namespace
 
-int launch_softmax_fwd(const float *A, int nmat, int N, int Np, float *F, float *Gt, void *Fb, void *Gtb,
+int launch_softmax_fwd(const float *A, int B, int Tm1, int N, int Np, float *F, float *Gt, void *Fb, void *Gtb,
                        float *stats, hipStream_t s) {
+  const int nmat = B * Tm1;
   float *rmax = stats, *rsum = stats + (long)nmat * Np, *cmax = stats + 2L * nmat * Np, *csum = stats + 3L * nmat * Np;
-  hipLaunchKernelGGL(row_stats_kernel, dim3((N + 3) / 4, nmat), dim3(256), 0, s, A, N, Np, rmax, rsum);
-  hipLaunchKernelGGL(col_stats_kernel, dim3((N + 63) / 64, nmat), dim3(256), 0, s, A, N, Np, cmax, csum);
-  hipLaunchKernelGGL(softmax_write_kernel, dim3(ew_blocks((long)Np * Np), nmat), dim3(256), 0, s, A, N, Np, rmax,
+  hipLaunchKernelGGL(row_stats_kernel, dim3((N + 3) / 4, nmat), dim3(256), 0, s, A, B, Tm1, N, Np, rmax, rsum);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((N + 63) / 64, nmat), dim3(256), 0, s, A, B, Tm1, N, Np, cmax, csum);
+  hipLaunchKernelGGL(softmax_write_kernel, dim3(ew_blocks((long)Np * Np), nmat), dim3(256), 0, s, A, B, Tm1, N, Np, rmax,
                      rsum, cmax, csum, F, Gt, (uint16_t *)Fb, (uint16_t *)Gtb);
   return check_launch();
 }
 
-int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const float *dGt, int nmat, int N, int Np,
-                       float *stats, float *dA, hipStream_t s) {
+int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const float *dGt, int B, int Tm1, int N,
+                       int Np, float *stats, float *dA, hipStream_t s) {
+  const int nmat = B * Tm1;
   float *rdot = stats, *cdot = stats + (long)nmat * Np;
   hipLaunchKernelGGL(row_dot_kernel, dim3((Np + 3) / 4, nmat), dim3(256), 0, s, F, dF, Np, rdot);
   hipLaunchKernelGGL(col_dot_kernel, dim3((Np + 63) / 64, nmat), dim3(256), 0, s, Gt, dGt, Np, cdot);
   hipLaunchKernelGGL(softmax_bwd_write_kernel, dim3(ew_blocks((long)N * N), nmat), dim3(256), 0, s, F, Gt, dF, dGt,
-                     rdot, cdot, N, Np, dA);
+                     rdot, cdot, B, Tm1, N, Np, dA);
   return check_launch();
 }
 

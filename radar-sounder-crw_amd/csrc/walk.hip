@@ -6,9 +6,13 @@
 //                          Lt_1 = Gt_0          Lt_{k+1} = Gt_k Lt_k       (Lt_k = L_k^T)
 //                          R_1  = I             R_{k+1}  = F_k  R_k
 //                          At_k = Lt_k^T R_k    loss = (1/N) sum_k mean_{b,d}(lse(At_k[d,:]) - At_k[d,d])
-//                      one grouped GEMM launch per k carries the three independent products.
-//   crw_walk_bwd     : reverse sweep, one grouped launch (four products, two of them fused
-//                      two-term accumulations) per k, then the dual-softmax backward.
+//                      Schedule: the two recurrences are the only sequential part (T-3 grouped launches
+//                      of 2 products, or ONE persistent LDS-resident kernel when Np <= 64); all
+//                      At_k are then independent and go out as one batched launch (batch (T-2)*B).
+//   crw_walk_bwd     : dAt for every k; one batched launch for the k-local terms (R_k dAt_k^T,
+//                      Lt_k dAt_k); the reverse recurrences (dLt_k += Gt_k^T dLt_{k+1},
+//                      dR_k += F_k^T dR_{k+1}) sequentially (or persistent kernel); one batched launch
+//                      for dGt_k = dLt_{k+1} Lt_k^T, dF_k = dR_{k+1} R_k^T; dual-softmax backward.
 //   crw_affinity_bwd : dE_t = (dA_t E_{t+1} + dA_{t-1}^T E_{t-1}) / tau, then normalise-backward.
 #include "crw_common.h"
 
@@ -105,8 +109,8 @@ WalkScratch layout_scratch(void *base, int B, int T, int N, int chain) {
   s.dAt = carve_mat(p, K * B * M, chain, true);
   s.dF = carve_mat(p, nA * M, chain, true, false);
   s.dGt = carve_mat(p, nA * M, chain, true, false);
-  s.dLt = carve_mat(p, 2 * (size_t)B * M, chain, true);  // fp32 needed: two-term accumulation across launches
-  s.dR = carve_mat(p, 2 * (size_t)B * M, chain, true);
+  s.dLt = carve_mat(p, K * B * M, chain, true);  // fp32 needed: accumulated in place (beta = 1)
+  s.dR = carve_mat(p, K * B * M, chain, true);
   s.stats = carve<float>(p, 2 * nA * Np);
   s.bytes = p - static_cast<char *>(base);
   return s;
@@ -147,9 +151,30 @@ void set_c(GemmProb &p, Opnd o) {
   p.Cbl = o.m->l ? o.m->l + o.off : nullptr;
   p.sC = o.stride;
 }
-int launch_group(const GemmGroup &g, int chain, hipStream_t s) {
+int launch_group_once(const GemmGroup &g, int chain, hipStream_t s) {
   if (chain == CRW_CHAIN_F32) return launch_gemm_group_f32(g, s);
   return launch_gemm_group_bf16(g, chain == CRW_CHAIN_BF16X3 ? 3 : 1, s);
+}
+// grid.y carries the batch: split very large batches
+int launch_group(const GemmGroup &g, int chain, hipStream_t s) {
+  constexpr int MAXB = 32768;
+  if (g.batch <= MAXB) return launch_group_once(g, chain, s);
+  const size_t es = chain == CRW_CHAIN_F32 ? 4 : 2;  // operand element size
+  for (int b0 = 0; b0 < g.batch; b0 += MAXB) {
+    GemmGroup sub = g;
+    sub.batch = g.batch - b0 < MAXB ? g.batch - b0 : MAXB;
+    for (int i = 0; i < g.nprob; ++i) {
+      GemmProb &q = sub.p[i];
+      auto adv = [&](const void *&ptr, long stride) { if (ptr) ptr = (const char *)ptr + (size_t)b0 * stride * es; };
+      adv(q.A, q.sA); adv(q.Al, q.sA); adv(q.B, q.sB); adv(q.Bl, q.sB);
+      adv(q.A2, q.sA2); adv(q.A2l, q.sA2); adv(q.B2, q.sB2); adv(q.B2l, q.sB2);
+      if (q.C) q.C += (long)b0 * q.sC;
+      if (q.Cb) q.Cb = (uint16_t *)q.Cb + (long)b0 * q.sC;
+      if (q.Cbl) q.Cbl = (uint16_t *)q.Cbl + (long)b0 * q.sC;
+    }
+    CRW_TRY(launch_group_once(sub, chain, s));
+  }
+  return CRW_OK;
 }
 // fp32 plane -> bf16 images of the same family (no-op for the fp32 chain)
 int make_images(const Mat &m, long count, hipStream_t s) {
@@ -220,39 +245,47 @@ int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, si
   WalkState st = layout_state(state, B, T, N, chain);
   if (state_bytes < st.bytes) return CRW_EWORKSPACE;
   const int Np = chain_padded_nodes(N, chain), K = T - 2, nA = B * (T - 1);
-  const long M = (long)Np * Np, SA = (long)(T - 1) * M;  // SA: batch stride inside F / Gt
+  const long M = (long)Np * Np, BM = (long)B * M;  // every family is [k][b][Np][Np]: k stride BM, batch stride M
+  const bool small = chain == CRW_CHAIN_F32 && Np <= 64;
 
-  CRW_TRY(launch_softmax_fwd(A, nA, N, Np, st.F.f, st.Gt.f, nullptr, nullptr, st.stats, s));
+  CRW_TRY(launch_softmax_fwd(A, B, T - 1, N, Np, st.F.f, st.Gt.f, nullptr, nullptr, st.stats, s));
   CRW_TRY(make_images(st.F, (long)nA * M, s));
   CRW_TRY(make_images(st.Gt, (long)nA * M, s));
   if (chain == CRW_CHAIN_F32) {
-    CRW_TRY(launch_copy_f32(st.Lt.f, st.Gt.f, M, SA, M, B, s));  // Lt_1 = Gt_0
+    CRW_TRY(launch_copy_f32(st.Lt.f, st.Gt.f, 0, 0, BM, 1, s));  // Lt_1 = Gt_0
     CRW_TRY(launch_identity(st.R.f, nullptr, B, Np, N, s));      // R_1 = I
   } else {  // the same on the bf16 images (two bf16 per float lane of the copy kernel)
-    CRW_TRY(launch_copy_f32((float *)st.Lt.h, (const float *)st.Gt.h, M / 2, SA / 2, M / 2, B, s));
-    if (st.Lt.l) CRW_TRY(launch_copy_f32((float *)st.Lt.l, (const float *)st.Gt.l, M / 2, SA / 2, M / 2, B, s));
+    CRW_TRY(launch_copy_f32((float *)st.Lt.h, (const float *)st.Gt.h, 0, 0, BM / 2, 1, s));
+    if (st.Lt.l) CRW_TRY(launch_copy_f32((float *)st.Lt.l, (const float *)st.Gt.l, 0, 0, BM / 2, 1, s));
     CRW_TRY(launch_identity(nullptr, st.R.h, B, Np, N, s));
-    if (st.R.l && hipMemsetAsync(st.R.l, 0, sizeof(uint16_t) * B * M, s) != hipSuccess) return CRW_EHIP;
+    if (st.R.l && hipMemsetAsync(st.R.l, 0, sizeof(uint16_t) * BM, s) != hipSuccess) return CRW_EHIP;
   }
 
-  for (int k = 1; k <= K; ++k) {
-    GemmGroup g{};
-    g.n = Np; g.batch = B;
-    const long ok = (long)(k - 1) * B * M;  // offset of Lt_k / R_k / At_k
-    GemmProb &p0 = g.p[g.nprob++];          // At_k = Lt_k^T R_k
-    set_a(p0, chain, {&st.Lt, ok, M}, 1);
-    set_b(p0, chain, {&st.R, ok, M}, 0);
-    set_c(p0, {&st.At, ok, M});
-    if (k < K) {
-      GemmProb &p1 = g.p[g.nprob++];  // Lt_{k+1} = Gt_k Lt_k
-      set_a(p1, chain, {&st.Gt, (long)k * M, SA}, 0);
-      set_b(p1, chain, {&st.Lt, ok, M}, 0);
-      set_c(p1, {&st.Lt, ok + (long)B * M, M});
-      GemmProb &p2 = g.p[g.nprob++];  // R_{k+1} = F_k R_k
-      set_a(p2, chain, {&st.F, (long)k * M, SA}, 0);
-      set_b(p2, chain, {&st.R, ok, M}, 0);
-      set_c(p2, {&st.R, ok + (long)B * M, M});
+  // the sequential part: Lt_{k+1} = Gt_k Lt_k, R_{k+1} = F_k R_k   (array index i holds X_{i+1})
+  if (small) {
+    CRW_TRY(launch_chain_small_fwd(st.Gt.f, st.F.f, st.Lt.f, st.R.f, B, K, Np, s));
+  } else {
+    for (int i = 1; i < K; ++i) {
+      GemmGroup g{};
+      g.n = Np; g.batch = B;
+      GemmProb &p1 = g.p[g.nprob++];
+      set_a(p1, chain, {&st.Gt, i * BM, M}, 0);
+      set_b(p1, chain, {&st.Lt, (i - 1) * BM, M}, 0);
+      set_c(p1, {&st.Lt, i * BM, M});
+      GemmProb &p2 = g.p[g.nprob++];
+      set_a(p2, chain, {&st.F, i * BM, M}, 0);
+      set_b(p2, chain, {&st.R, (i - 1) * BM, M}, 0);
+      set_c(p2, {&st.R, i * BM, M});
+      CRW_TRY(launch_group(g, chain, s));
     }
+  }
+  {  // every cycle product at once: At_k = Lt_k^T R_k, batch K*B
+    GemmGroup g{};
+    g.n = Np; g.batch = K * B;
+    GemmProb &p0 = g.p[g.nprob++];
+    set_a(p0, chain, {&st.Lt, 0, M}, 1);
+    set_b(p0, chain, {&st.R, 0, M}, 0);
+    set_c(p0, {&st.At, 0, M});
     CRW_TRY(launch_group(g, chain, s));
   }
   CRW_TRY(launch_loss_rows(st.At.f, K * B, N, Np, st.lse, st.terms, s));
@@ -275,47 +308,67 @@ int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state
   WalkState st = layout_state(state, B, T, N, chain);
   WalkScratch sc = layout_scratch(scratch, B, T, N, chain);
   if (state_bytes < st.bytes || scratch_bytes < sc.bytes) return CRW_EWORKSPACE;
-  const int Np = chain_padded_nodes(N, chain), K = T - 2, nA = B * (T - 1);
-  const long M = (long)Np * Np, SA = (long)(T - 1) * M;
+  const int Np = chain_padded_nodes(N, chain), K = T - 2;
+  const long M = (long)Np * Np, BM = (long)B * M;
+  const bool small = chain == CRW_CHAIN_F32 && Np <= 64;
 
   const float coef = 1.0f / ((float)N * (float)B * (float)N);
   CRW_TRY(launch_dAt(st.At.f, st.lse, gloss, coef, K * B, N, Np, sc.dAt.f, nullptr, s));
-  CRW_TRY(make_images(sc.dAt, (long)K * B * M, s));
-  if (hipMemsetAsync(sc.dF.f, 0, sizeof(float) * nA * M, s) != hipSuccess) return CRW_EHIP;
-  if (hipMemsetAsync(sc.dGt.f, 0, sizeof(float) * nA * M, s) != hipSuccess) return CRW_EHIP;
+  CRW_TRY(make_images(sc.dAt, K * BM, s));
+  // slices no product writes: dF_0, dF_{T-2}, dGt_{T-2}
+  if (hipMemsetAsync(sc.dF.f, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
+  if (hipMemsetAsync(sc.dF.f + (long)(T - 2) * BM, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
+  if (hipMemsetAsync(sc.dGt.f + (long)(T - 2) * BM, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
 
-  for (int k = K; k >= 1; --k) {
+  {  // k-local terms for every k at once: dLt_k = R_k dAt_k^T, dR_k = Lt_k dAt_k
     GemmGroup g{};
-    g.n = Np; g.batch = B;
-    const long ok = (long)(k - 1) * B * M;
-    const long cur = (long)(k & 1) * B * M, nxt = (long)((k + 1) & 1) * B * M;
-    GemmProb &p0 = g.p[g.nprob++];  // dLt_k = R_k dAt_k^T (+ Gt_k^T dLt_{k+1})
-    set_a(p0, chain, {&st.R, ok, M}, 0);
-    set_b(p0, chain, {&sc.dAt, ok, M}, 1);
-    set_c(p0, {&sc.dLt, cur, M});
-    GemmProb &p1 = g.p[g.nprob++];  // dR_k = Lt_k dAt_k (+ F_k^T dR_{k+1})
-    set_a(p1, chain, {&st.Lt, ok, M}, 0);
-    set_b(p1, chain, {&sc.dAt, ok, M}, 0);
-    set_c(p1, {&sc.dR, cur, M});
-    if (k < K) {
-      set_a2(p0, chain, {&st.Gt, (long)k * M, SA}, 1);
-      set_b2(p0, chain, {&sc.dLt, nxt, M}, 0);
-      set_a2(p1, chain, {&st.F, (long)k * M, SA}, 1);
-      set_b2(p1, chain, {&sc.dR, nxt, M}, 0);
-      GemmProb &p2 = g.p[g.nprob++];  // dGt_k = dLt_{k+1} Lt_k^T
-      set_a(p2, chain, {&sc.dLt, nxt, M}, 0);
-      set_b(p2, chain, {&st.Lt, ok, M}, 1);
-      set_c(p2, {&sc.dGt, (long)k * M, SA});
-      GemmProb &p3 = g.p[g.nprob++];  // dF_k = dR_{k+1} R_k^T
-      set_a(p3, chain, {&sc.dR, nxt, M}, 0);
-      set_b(p3, chain, {&st.R, ok, M}, 1);
-      set_c(p3, {&sc.dF, (long)k * M, SA});
+    g.n = Np; g.batch = K * B;
+    GemmProb &p0 = g.p[g.nprob++];
+    set_a(p0, chain, {&st.R, 0, M}, 0);
+    set_b(p0, chain, {&sc.dAt, 0, M}, 1);
+    set_c(p0, {&sc.dLt, 0, M});
+    GemmProb &p1 = g.p[g.nprob++];
+    set_a(p1, chain, {&st.Lt, 0, M}, 0);
+    set_b(p1, chain, {&sc.dAt, 0, M}, 0);
+    set_c(p1, {&sc.dR, 0, M});
+    CRW_TRY(launch_group(g, chain, s));
+  }
+  // the sequential part: dLt_k += Gt_k^T dLt_{k+1}, dR_k += F_k^T dR_{k+1}   (index i holds X_{i+1})
+  if (small) {
+    CRW_TRY(launch_chain_small_bwd(st.Gt.f, st.F.f, sc.dLt.f, sc.dR.f, B, K, Np, s));
+  } else {
+    for (int i = K - 2; i >= 0; --i) {
+      GemmGroup g{};
+      g.n = Np; g.batch = B;
+      GemmProb &p0 = g.p[g.nprob++];
+      set_a(p0, chain, {&st.Gt, (i + 1) * BM, M}, 1);
+      set_b(p0, chain, {&sc.dLt, (i + 1) * BM, M}, 0);
+      set_c(p0, {&sc.dLt, i * BM, M});
+      p0.beta = 1;
+      GemmProb &p1 = g.p[g.nprob++];
+      set_a(p1, chain, {&st.F, (i + 1) * BM, M}, 1);
+      set_b(p1, chain, {&sc.dR, (i + 1) * BM, M}, 0);
+      set_c(p1, {&sc.dR, i * BM, M});
+      p1.beta = 1;
+      CRW_TRY(launch_group(g, chain, s));
     }
+  }
+  if (K > 1) {  // dGt_k = dLt_{k+1} Lt_k^T, dF_k = dR_{k+1} R_k^T for k = 1..K-1, batch (K-1)*B
+    GemmGroup g{};
+    g.n = Np; g.batch = (K - 1) * B;
+    GemmProb &p2 = g.p[g.nprob++];
+    set_a(p2, chain, {&sc.dLt, BM, M}, 0);
+    set_b(p2, chain, {&st.Lt, 0, M}, 1);
+    set_c(p2, {&sc.dGt, BM, M});
+    GemmProb &p3 = g.p[g.nprob++];
+    set_a(p3, chain, {&sc.dR, BM, M}, 0);
+    set_b(p3, chain, {&st.R, 0, M}, 1);
+    set_c(p3, {&sc.dF, BM, M});
     CRW_TRY(launch_group(g, chain, s));
   }
   // Lt_1 = Gt_0  ->  dGt_0 = dLt_1
-  CRW_TRY(launch_copy_f32(sc.dGt.f, sc.dLt.f + (long)(1 & 1) * B * M, SA, M, M, B, s));
-  CRW_TRY(launch_softmax_bwd(st.F.f, st.Gt.f, sc.dF.f, sc.dGt.f, nA, N, Np, sc.stats, dA, s));
+  CRW_TRY(launch_copy_f32(sc.dGt.f, sc.dLt.f, 0, 0, BM, 1, s));
+  CRW_TRY(launch_softmax_bwd(st.F.f, st.Gt.f, sc.dF.f, sc.dGt.f, B, T - 1, N, Np, sc.stats, dA, s));
   return CRW_OK;
 }
 
