@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", type=int, default=0, help="0 = CNN (BASELINE 'tiny CNN encoder'), 1 = Resnet")
+    ap.add_argument("--convs", default="bf16x3", choices=["bf16x3", "bf16", "torch"],
+                    help="conv3-5 of the CNN: bf16x3 = HIP kernels, hi/lo bf16 operand pairs (fp32-grade, default); "
+                         "bf16 = HIP kernels, plain bf16 operands; torch = PyTorch-ROCm (MIOpen) fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
@@ -72,6 +75,30 @@ def chain_probe(n, batch, nprob, iters=50):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * n ** 3 * batch * nprob
     return ms, flops
+
+
+def walk_probe(B, T, N, iters=20):
+    """Affinity + walk fwd+bwd alone (features resident), fp32 chain, at the radargram workload's shape."""
+    import crw_hip
+    import model as crw_model
+    g = torch.Generator().manual_seed(3)
+    emb0 = torch.randn(B, T, N, 128, generator=g).cuda()
+
+    def step():
+        emb = emb0.clone().requires_grad_(True)
+        crw_model.walk_loss(crw_model.affinity(emb, TAU)).backward()
+
+    for _ in range(3):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    Np = crw_hip.padded_nodes(N)
+    return ms, 2.0 * Np ** 3 * (9 * (T - 3) + 3) * B
 
 
 def chain_probe_bf16(n, batch, split, iters=10):
@@ -197,6 +224,8 @@ def main():
 
     torch.manual_seed(11)
     enc = crw_utils.create_model(args.model, False)
+    if args.model == 0:
+        enc.hip_convs = None if args.convs == "torch" else args.convs
     net = crw_model.CRW(enc, TAU, False).to(device)
     net.train(True)
     bucket = crw_dist.FlatGradBucket(net.parameters())
@@ -239,12 +268,14 @@ def main():
             "metric": "radargram columns/sec (CRW fwd+bwd)", "value": cols_per_step * world / (elapsed / args.steps),
             "unit": "radargram columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"bf16x3": "f32 (conv3-5 and nothing else on bf16 hi/lo pairs, fp32 accumulate: fp32-grade)",
+                      "bf16": "bf16 (conv3-5 operands), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else "torch"],
+            "data": "synthetic",
             "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
                                    f"[T={T},N={N},16x16] (patch 16x16, overlap (8,0)), tau={TAU}, "
                                    f"{'CNN' if args.model == 0 else 'Resnet'} encoder, fwd+bwd+all-reduce+Adam",
                        "columns_per_step_per_gpu": cols_per_step, "parallelism": f"dp{world} (independent sequences)",
-                       "chain": "fp32 MFMA 16x16x4, prefix form", "loss": final_loss},
+                       "chain": "fp32 MFMA 16x16x4, prefix form", "encoder_convs": args.convs, "loss": final_loss},
         }
         if not args.no_probe:
             Np = crw_hip.padded_nodes(N)
@@ -253,6 +284,10 @@ def main():
                                "bound": "mfma", "achieved": pfl / (pms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f32"],
                                "unit": "TFLOP/s", "frac": pfl / (pms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"],
                                "traffic": None, "launch_us": pms * 1e3, "shape": f"n={Np} batch={B}x3"}
+            wms, wfl = walk_probe(B, T, N)
+            out["walk_at_workload_shape"] = {"what": "affinity + dual softmax + chain + loss, fwd+bwd, features resident",
+                                             "ms": wms, "chain_tflops": wfl / (wms * 1e-3) / 1e12,
+                                             "share_of_step": wms / ms}
             kms, kfl = chain_probe(4096, 1, 3, iters=5)
             out["roofline_chain_n4096"] = {"kernel": "gemm_pad_f32_kernel", "bound": "mfma",
                                            "achieved": kfl / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f32"],

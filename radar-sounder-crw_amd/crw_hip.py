@@ -36,6 +36,11 @@ SIGNATURES = {
     "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
     "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
+    "crw_enc_pack_weights": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
+    "crw_enc_conv3x3": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p]),
+    "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -183,3 +188,68 @@ def gemm_bf16(A, B, C=None, transA=False, transB=False, beta=False, split=1, ws=
                                int(beta), int(split), ctypes.c_void_p(ws.data_ptr()), ws.numel(), int(convert),
                                _stream()), "crw_gemm_bf16")
     return C, ws
+
+
+# ------------------------------------------------------------------------------ encoder conv stack
+_BF = torch.bfloat16
+
+
+def _bf(t, name):
+    return _dev(t, name, _BF) if t is not None else None
+
+
+def enc_pack_weights(w, split):
+    """fp32 conv weight [cout,cin,3,3] -> (fwd_hi, fwd_lo, bwd_hi, bwd_lo) bf16 planes (lo = None for split 1)."""
+    cout, cin = w.shape[:2]
+    mk = lambda a, b: torch.empty(9, a, b, dtype=_BF, device=w.device)
+    fh, bh = mk(cout, cin), mk(cin, cout)
+    fl, bl = (mk(cout, cin), mk(cin, cout)) if split == 3 else (None, None)
+    _check(lib().crw_enc_pack_weights(_dev(w.contiguous(), "w"), cout, cin, _bf(fh, "fh"), _bf(fl, "fl"), _bf(bh, "bh"),
+                                      _bf(bl, "bl"), _stream()), "crw_enc_pack_weights")
+    return fh, fl, bh, bl
+
+
+def enc_pack_input(x, split):
+    """fp32 NCHW [P,C,10,10] -> channels-last planes [P,144,C] with zero halo."""
+    P, C, H, W = x.shape
+    if (H, W) != (10, 10):
+        raise RuntimeError(f"the HIP conv stack handles 10x10 feature maps (16x16 patches), got {H}x{W}")
+    xh = torch.empty(P, 144, C, dtype=_BF, device=x.device)
+    xl = torch.empty_like(xh) if split == 3 else None
+    _check(lib().crw_enc_pack_input(_dev(x.contiguous(), "x"), P, C, _bf(xh, "xh"), _bf(xl, "xl"), _stream()),
+           "crw_enc_pack_input")
+    return xh, xl
+
+
+def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=True, f32=False, gap=False):
+    """mode 0: relu(conv + bias) ; mode 1: backward-data with optional ReLU mask.  -> (yh, yl, yf, gap)"""
+    P, _, cin = xh.shape
+    dev = xh.device
+    yh = torch.empty(P, 144, cout, dtype=_BF, device=dev) if planes else None
+    yl = torch.empty_like(yh) if (planes and split == 3) else None
+    yf = torch.empty(P, 100, cout, dtype=torch.float32, device=dev) if f32 else None
+    gp = torch.empty(P, cout, dtype=torch.float32, device=dev) if gap else None
+    _check(lib().crw_enc_conv3x3(mode, split, P, cin, cout, _bf(xh, "xh"), _bf(xl, "xl"), _bf(wh, "wh"), _bf(wl, "wl"),
+                                 _dev(bias, "bias") if bias is not None else None, _bf(mask, "mask"), _bf(yh, "yh"),
+                                 _bf(yl, "yl"), _dev(yf, "yf") if f32 else None, _dev(gp, "gap") if gap else None,
+                                 _stream()), "crw_enc_conv3x3")
+    return yh, yl, yf, gp
+
+
+def enc_gap_bwd(dgap, yh, split):
+    P, _, C = yh.shape
+    dh = torch.empty_like(yh)
+    dl = torch.empty_like(yh) if split == 3 else None
+    _check(lib().crw_enc_gap_bwd(_dev(dgap.contiguous(), "dgap"), _bf(yh, "yh"), P, C, _bf(dh, "dh"), _bf(dl, "dl"),
+                                 _stream()), "crw_enc_gap_bwd")
+    return dh, dl
+
+
+def enc_wgrad(split, dyh, dyl, xh, xl):
+    P, _, cout = dyh.shape
+    cin = xh.shape[2]
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=xh.device)
+    db = torch.empty(cout, dtype=torch.float32, device=xh.device)
+    _check(lib().crw_enc_conv3x3_wgrad(split, P, cin, cout, _bf(dyh, "dyh"), _bf(dyl, "dyl"), _bf(xh, "xh"),
+                                       _bf(xl, "xl"), _dev(dw, "dw"), _dev(db, "db"), _stream()), "crw_enc_conv3x3_wgrad")
+    return dw, db

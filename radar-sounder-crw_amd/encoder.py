@@ -3,15 +3,52 @@
 so checkpoints are interchangeable and, with the same ``torch.manual_seed``, the initial weights
 are identical (layers are constructed in the same order, so the RNG stream is consumed alike).
 
-The arithmetic here is PyTorch-ROCm (MIOpen convolutions): per BASELINE.json's north_star the
-encoder is "Python host code on PyTorch-ROCm"; the hand-written HIP kernels start at the encoder
-output (model.py -> crw_hip).
+Arithmetic: conv1/pool1/conv2/pool2 and the linear head are PyTorch-ROCm ops (3.3 % of the
+encoder's flops).  On an MI355X, for 16x16 patches, the three 3x3 layers conv3/conv4/conv5 (+ReLU)
+and the global average pool -- 96.7 % of the flops, forward AND backward -- run in the hand-written
+implicit-GEMM MFMA kernels of csrc/encoder_conv.hip (``CNN.hip_convs``: "bf16x3" = hi/lo bf16
+operand pairs, fp32-grade results, the default; "bf16" = plain bf16 operands; None = PyTorch ops).
+``Resnet`` is PyTorch-ROCm throughout.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
 FEATURE_DIM = 128
+
+
+class _HipConv345(torch.autograd.Function):
+    """relu(conv5(relu(conv4(relu(conv3(x)))))) followed by the global average pool, on the HIP kernels.
+    x: [P,32,10,10] fp32 (output of pool2) -> [P,128] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3, w4, b4, w5, b5, split):
+        import crw_hip
+        packed = [crw_hip.enc_pack_weights(w, split) for w in (w3, w4, w5)]
+        x3h, x3l = crw_hip.enc_pack_input(x, split)
+        y3h, y3l, _, _ = crw_hip.enc_conv3x3(0, split, x3h, x3l, packed[0][0], packed[0][1], 64, bias=b3)
+        y4h, y4l, _, _ = crw_hip.enc_conv3x3(0, split, y3h, y3l, packed[1][0], packed[1][1], 128, bias=b4)
+        y5h, _, _, gap = crw_hip.enc_conv3x3(0, split, y4h, y4l, packed[2][0], packed[2][1], 128, bias=b5, gap=True)
+        ctx.split = split
+        ctx.planes = (x3h, x3l, y3h, y3l, y4h, y4l, y5h)
+        ctx.bwd_w = [(pk[2], pk[3]) for pk in packed]
+        return gap
+
+    @staticmethod
+    def backward(ctx, dgap):
+        import crw_hip
+        s = ctx.split
+        x3h, x3l, y3h, y3l, y4h, y4l, y5h = ctx.planes
+        d5h, d5l = crw_hip.enc_gap_bwd(dgap, y5h, s)                        # dY5 (ReLU5 + GAP backward)
+        dw5, db5 = crw_hip.enc_wgrad(s, d5h, d5l, y4h, y4l)
+        d4h, d4l, _, _ = crw_hip.enc_conv3x3(1, s, d5h, d5l, *ctx.bwd_w[2], 128, mask=y4h)   # dY4 (masked by ReLU4)
+        dw4, db4 = crw_hip.enc_wgrad(s, d4h, d4l, y3h, y3l)
+        d3h, d3l, _, _ = crw_hip.enc_conv3x3(1, s, d4h, d4l, *ctx.bwd_w[1], 64, mask=y3h)    # dY3
+        dw3, db3 = crw_hip.enc_wgrad(s, d3h, d3l, x3h, x3l)
+        _, _, dx, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *ctx.bwd_w[0], 32, planes=False, f32=True)
+        ctx.planes = None
+        P = dx.shape[0]
+        return dx.view(P, 10, 10, 32).permute(0, 3, 1, 2), dw3, db3, dw4, db4, dw5, db5, None
 
 # (name, out_channels, kernel, followed by 2x2/stride-1 max-pool?)
 _CNN_STACK = (("1", 8, 5, True), ("2", 32, 5, True), ("3", 64, 3, False), ("4", 128, 3, False), ("5", 128, 3, False))
@@ -39,8 +76,15 @@ class CNN(nn.Module):
         self.global_avg_pool = nn.AdaptiveAvgPool2d(1)
         self.fc = nn.Linear(cin, FEATURE_DIM)
         self.num_params = _report(self)
+        self.hip_convs = "bf16x3"  # "bf16x3" | "bf16" | None (PyTorch ops); only used on an MI355X
 
     def forward(self, x):
+        if self.hip_convs and x.is_cuda and x.shape[-2:] == (16, 16) and x.dtype == torch.float32:
+            x = self.pool1(self.relu1(self.conv1(x)))
+            x = self.pool2(self.relu2(self.conv2(x)))  # [P,32,10,10]
+            gap = _HipConv345.apply(x, self.conv3.weight, self.conv3.bias, self.conv4.weight, self.conv4.bias,
+                                    self.conv5.weight, self.conv5.bias, 3 if self.hip_convs == "bf16x3" else 1)
+            return self.fc(gap)
         for name, _, _, pooled in _CNN_STACK:
             x = getattr(self, "relu" + name)(getattr(self, "conv" + name)(x))
             if pooled:
