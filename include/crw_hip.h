@@ -132,9 +132,13 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
 /* dY planes [P][144][C] = dgap[P][C] / 100 where y_hi != 0 (backward of ReLU + global average pool) */
 int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
                     crw_stream_t stream);
-/* dw [cout][cin][3][3], db [cout] (fp32, overwritten) from dY planes [P][144][cout] and x planes [P][144][cin] */
+/* dw [cout][cin][3][3], db [cout] (fp32, overwritten) from dY planes [P][144][cout] and x planes [P][144][cin].
+ * Per-slice partial sums go to `ws` (crw_enc_wgrad_ws_bytes) and are added in a fixed order:
+ * no float atomics, bitwise reproducible. */
+size_t crw_enc_wgrad_ws_bytes(int P, int cin, int cout, int split);
 int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
-                          const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, crw_stream_t stream);
+                          const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, void *ws,
+                          size_t ws_bytes, crw_stream_t stream);
 
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous

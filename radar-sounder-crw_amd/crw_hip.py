@@ -40,7 +40,8 @@ SIGNATURES = {
     "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "crw_enc_conv3x3": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p]),
-    "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_wgrad_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -250,6 +251,9 @@ def enc_wgrad(split, dyh, dyl, xh, xl):
     cin = xh.shape[2]
     dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=xh.device)
     db = torch.empty(cout, dtype=torch.float32, device=xh.device)
+    nbytes = lib().crw_enc_wgrad_ws_bytes(P, cin, cout, split)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xh.device)
     _check(lib().crw_enc_conv3x3_wgrad(split, P, cin, cout, _bf(dyh, "dyh"), _bf(dyl, "dyl"), _bf(xh, "xh"),
-                                       _bf(xl, "xl"), _dev(dw, "dw"), _dev(db, "db"), _stream()), "crw_enc_conv3x3_wgrad")
+                                       _bf(xl, "xl"), _dev(dw, "dw"), _dev(db, "db"), ctypes.c_void_p(ws.data_ptr()),
+                                       nbytes, _stream()), "crw_enc_conv3x3_wgrad")
     return dw, db

@@ -25,6 +25,7 @@
 // taps), walks a slice of the patches accumulating in registers, then adds its partial sums to
 // the fp32 gradient with atomics.
 #include "crw_common.h"
+#include <type_traits>
 
 namespace crw {
 namespace {
@@ -39,13 +40,39 @@ typedef __attribute__((address_space(3))) char *lds_cp;
 __device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
-// byte offset of 16-byte chunk `chunk` of pixel `pp` in an LDS plane with C channels
+// LDS planes: pixel rows are padded by one 16-byte chunk (stride 2C + 16 bytes), so that the 16
+// pixels of an MFMA row tile -- or the 8 pixel rows of a transposed read -- start in different
+// banks, while every chunk offset stays a compile-time constant (an XOR swizzle costs VALU work
+// per fragment read; with padding the reads of one k-step share one address register).
 template <int C>
-__device__ inline int px_off(int pp, int chunk) {
-  constexpr int NCH = C / 8;                             // chunks per pixel
-  constexpr int RPB = (C * 2 >= 256) ? 1 : 256 / (C * 2);  // pixels per 256-byte bank row
-  return pp * (C * 2) + 16 * (chunk ^ ((pp / RPB) % NCH));
-}
+constexpr int row_stride() { return C * 2 + 16; }
+template <int C>
+constexpr int plane_bytes() { return NPAD * row_stride<C>(); }
+template <int C>
+__device__ inline int px_off(int pp, int chunk) { return pp * row_stride<C>() + 16 * chunk; }
+
+// global plane [144][C] (one patch) -> LDS plane.  load() only issues the global loads, store()
+// writes LDS: callers issue the loads of ALL planes first, so one HBM round trip covers them all
+// (load-wait-store per plane, or per 16 bytes, exposes one round trip each).
+template <int C, int NTHREADS>
+struct PlaneLoad {
+  static constexpr int NCH = C / 8, TOTAL = NPAD * NCH, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  uint4 v[ITER];
+  __device__ inline void load(const uint16_t *__restrict__ src, int tid) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int c = tid + i * NTHREADS;
+      if (TOTAL % NTHREADS == 0 || c < TOTAL) v[i] = *reinterpret_cast<const uint4 *>(src + (long)c * 8);
+    }
+  }
+  __device__ inline void store(char *dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int c = tid + i * NTHREADS;
+      if (TOTAL % NTHREADS == 0 || c < TOTAL) *reinterpret_cast<uint4 *>(dst + px_off<C>(c / NCH, c % NCH)) = v[i];
+    }
+  }
+};
 
 struct ConvArgs {
   const uint16_t *xh, *xl;   // [P][144][CIN] input planes (zero halo)
@@ -62,7 +89,7 @@ template <int SPLIT, int CIN, int COUT, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
-  constexpr int PLANE = NPAD * CMAX * 2;  // bytes per LDS plane (input image, later output staging)
+  constexpr int PLANE = plane_bytes<CMAX>();  // bytes per LDS plane (input image, later output staging)
   constexpr int WN = (COUT / 16 >= 4) ? 4 : COUT / 16;  // waves across the output channels
   constexpr int WM = 4 / WN;                            // waves across the pixel row tiles
   constexpr int NTW = COUT / 16 / WN;                   // 16-wide column tiles per wave
@@ -76,15 +103,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 
   // ---- patch -> LDS (swizzled) ---------------------------------------------------------------
   {
-    constexpr int NCH = CIN / 8, TOTAL = NPAD * NCH;
-    for (int pl = 0; pl < NPL; ++pl) {
-      const uint16_t *src = (pl ? a.xl : a.xh) + (long)p * NPAD * CIN;
-      char *dst = lds + pl * PLANE;
-      for (int c = tid; c < TOTAL; c += 256) {
-        const int pix = c / NCH, ch = c % NCH;
-        *reinterpret_cast<uint4 *>(dst + px_off<CIN>(pix, ch)) = *reinterpret_cast<const uint4 *>(src + (long)c * 8);
-      }
-    }
+    PlaneLoad<CIN, 256> lh, ll;
+    lh.load(a.xh + (long)p * NPAD * CIN, tid);
+    if (SPLIT == 3) ll.load(a.xl + (long)p * NPAD * CIN, tid);
+    lh.store(lds, tid);
+    if (SPLIT == 3) ll.store(lds + PLANE, tid);
   }
   __syncthreads();
 
@@ -116,13 +139,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   };
 
   constexpr int NSTEP = 9 * KCH;
+  constexpr int AHEAD = 3;  // weight fragments are requested 3 k-steps (~2k cycles) before use: L2 latency under load
   auto do_step = [&](int step, bf8 (&bhc)[NTW], bf8 (&blc)[NTW], bf8 (&bhn)[NTW], bf8 (&bln)[NTW]) {
-    if (step + 1 < NSTEP) load_b(step + 1, bhn, bln);  // weights of the next k-step stream in behind the MFMAs
+    if (step + AHEAD < NSTEP) load_b(step + AHEAD, bhn, bln);
     const int tap = step / KCH, cc = step % KCH;
     const int toff = (tap / 3) * PAD_W + (tap % 3);
 #pragma unroll
     for (int k = 0; k < MTW; ++k) {
-      if (wm + WM * k < MT) {  // wave-uniform
+      if (WM == 1 || wm + WM * k < MT) {  // wave-uniform
         const int pp = pp0[k] + toff;
         const bf8 ah = *reinterpret_cast<const bf8 *>(lds + px_off<CIN>(pp, 4 * cc + g));
         bf8 al;
@@ -138,24 +162,34 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       }
     }
   };
-  // two register sets for the weight fragments, addressed statically (a run-time index would send
-  // them to scratch)
-  bf8 bh0[NTW], bl0[NTW], bh1[NTW], bl1[NTW];
+  // four register sets for the weight fragments, rotated with static indices (a run-time index
+  // would send them to scratch): step s uses set s % 4 and refills set (s + 3) % 4
+  bf8 bh0[NTW], bl0[NTW], bh1[NTW], bl1[NTW], bh2[NTW], bl2[NTW], bh3[NTW], bl3[NTW];
   load_b(0, bh0, bl0);
-  for (int step = 0; step + 1 < NSTEP; step += 2) {
-    do_step(step, bh0, bl0, bh1, bl1);
+  if (NSTEP > 1) load_b(1, bh1, bl1);
+  if (NSTEP > 2) load_b(2, bh2, bl2);
+  int step = 0;
+  for (; step + 4 <= NSTEP; step += 4) {
+    do_step(step, bh0, bl0, bh3, bl3);
     do_step(step + 1, bh1, bl1, bh0, bl0);
+    do_step(step + 2, bh2, bl2, bh1, bl1);
+    do_step(step + 3, bh3, bl3, bh2, bl2);
   }
-  if (NSTEP & 1) do_step(NSTEP - 1, bh0, bl0, bh1, bl1);
+  if (NSTEP % 4 >= 1) do_step(step, bh0, bl0, bh3, bl3);
+  if (NSTEP % 4 >= 2) do_step(step + 1, bh1, bl1, bh0, bl0);
+  if (NSTEP % 4 >= 3) do_step(step + 2, bh2, bl2, bh1, bl1);
 
   // ---- epilogue ----------------------------------------------------------------------------------
   // C/D map: acc[k][j][r] = out[pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
-  float gsum[NTW];
+  float gsum[NTW], bias_r[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) gsum[j] = 0.f;
+  for (int j = 0; j < NTW; ++j) {
+    gsum[j] = 0.f;
+    bias_r[j] = (MODE == 0 && a.bias) ? a.bias[co_w + 16 * j + r16] : 0.f;
+  }
   __syncthreads();  // every wave is done reading the input image: reuse LDS as the output staging
   if (a.yh) {       // zero the staging planes (the halo stays zero)
-    constexpr int OUTB = NPAD * COUT * 2;
+    constexpr int OUTB = plane_bytes<COUT>();
     for (int pl = 0; pl < NPL; ++pl)
       for (int c = tid; c < OUTB / 16; c += 256) *reinterpret_cast<uint4 *>(lds + pl * PLANE + 16 * c) = uint4{0, 0, 0, 0};
     __syncthreads();
@@ -172,11 +206,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
           const int pp = (i / IMG_W + 1) * PAD_W + (i % IMG_W + 1);
           float v = acc[k][j][r];
           if (MODE == 0) {
-            if (a.bias) v += a.bias[co];
-            v = fmaxf(v, 0.f);
+            v = fmaxf(v + bias_r[j], 0.f);
             gsum[j] += v;
-          } else if (a.maskh) {
-            if ((a.maskh[((long)p * NPAD + pp) * COUT + co] & 0x7fff) == 0) v = 0.f;
           }
           if (a.yf) a.yf[((long)p * NPIX + i) * COUT + co] = v;
           if (a.yh) {
@@ -199,13 +230,38 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   }
   if (a.yh) {
     __syncthreads();
-    constexpr int NCH = COUT / 8, TOTAL = NPAD * NCH;
+    // staged tile -> global in whole 16-byte chunks; the ReLU mask of the layer below (MODE 1) is
+    // applied here, 8 channels at a time, from the matching chunk of its activation plane
+    constexpr int NCH = COUT / 8, TOTAL = NPAD * NCH, ITER = (TOTAL + 255) / 256;
+    const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (long)p * NPAD * COUT : nullptr;
+    uint4 mv[ITER];
+    if (mk) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int c = tid + it * 256;
+        if (c < TOTAL) mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
+      }
+    }
     for (int pl = 0; pl < NPL; ++pl) {
       uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPAD * COUT;
       const char *src = lds + pl * PLANE;
-      for (int c = tid; c < TOTAL; c += 256) {
-        const int pix = c / NCH, ch = c % NCH;
-        *reinterpret_cast<uint4 *>(dst + (long)c * 8) = *reinterpret_cast<const uint4 *>(src + px_off<COUT>(pix, ch));
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int c = tid + it * 256;
+        if (c < TOTAL) {
+          uint4 v = *reinterpret_cast<const uint4 *>(src + px_off<COUT>(c / NCH, c % NCH));
+          if (mk) {  // keep a bf16 lane only where the mask lane is non-zero
+            const uint32_t m[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
+            uint32_t o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const uint32_t keep = ((m[w] & 0x7fffu) ? 0xffffu : 0u) | ((m[w] & 0x7fff0000u) ? 0xffff0000u : 0u);
+              o[w] &= keep;
+            }
+            v = uint4{o[0], o[1], o[2], o[3]};
+          }
+          *reinterpret_cast<uint4 *>(dst + (long)c * 8) = v;
+        }
       }
     }
   }
@@ -217,26 +273,25 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 struct WgradArgs {
   const uint16_t *dyh, *dyl;  // [P][144][COUT] masked output gradient planes (zero halo)
   const uint16_t *xh, *xl;    // [P][144][CIN] layer input planes (zero halo)
-  float *dw;                  // [COUT][CIN][3][3] fp32, accumulated with atomics (pre-zeroed)
-  float *db;                  // [COUT] fp32, accumulated with atomics (pre-zeroed)
+  float *dw_part;             // [nslice][COUT][CIN][3][3] fp32 partial sums (every element written)
+  float *db_part;             // [nslice][3][COUT] fp32 partial sums
   int P, patches_per_block;
 };
 
+template <int IMM>
 __device__ inline s4v tr_read(uint32_t lds_addr) {
   s4v v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(IMM) : "memory");
   return v;
 }
 
-// transposed fragment: 8 consecutive "rows" (pixels, the reduction index) x 16 channels starting at c0,
-// from a plane [pixel][C] swizzled with px_off<C>; rowpix(q) gives the pixel of fragment row 8g+q
-template <int C, typename F>
-__device__ inline bf8 tr_frag(uint32_t plane, int c0, int lane, F rowpix) {
-  const int t = lane & 15, q = t >> 2, pq = t & 3;
-  const int chunk = (c0 >> 3) + (pq >> 1);
-  const int p_lo = rowpix(q), p_hi = rowpix(q + 4);
-  const s4v lo = tr_read(plane + px_off<C>(p_lo, chunk) + 8 * (pq & 1));
-  const s4v hi = tr_read(plane + px_off<C>(p_hi, chunk) + 8 * (pq & 1));
+// transposed fragment: 8 reduction rows (pixels) x the 16 channels starting at channel C0.  a_lo / a_hi
+// are this lane's LDS byte addresses of fragment rows 8g+q and 8g+q+4 (already including the lane's
+// 8*(pq&1) + 16*(pq>>1) column part); C0 and the plane offset enter as an instruction immediate.
+template <int IMM>
+__device__ inline bf8 tr_frag(uint32_t a_lo, uint32_t a_hi) {
+  const s4v lo = tr_read<IMM>(a_lo);
+  const s4v hi = tr_read<IMM>(a_hi);
   const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf8, v);
 }
@@ -244,7 +299,7 @@ __device__ inline bf8 tr_frag(uint32_t plane, int c0, int lane, F rowpix) {
 template <int SPLIT, int CIN, int COUT>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
-  constexpr int XPL = NPAD * CIN * 2, YPL = NPAD * COUT * 2;  // bytes per plane
+  constexpr int XPL = plane_bytes<CIN>(), YPL = plane_bytes<COUT>();  // bytes per LDS plane
   constexpr int MTW = COUT / 128 > 0 ? COUT / 128 : 1;        // 16-wide co tiles per wave (8 waves)
   constexpr int COW = COUT / 8;                               // co per wave (16 or 8 -> see below)
   static_assert(COUT % 128 == 0 || COUT == 64, "COUT");
@@ -276,72 +331,93 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();  // previous patch fully consumed
     {
-      constexpr int NCX = CIN / 8, NCY = COUT / 8;
-      for (int pl = 0; pl < NPL; ++pl) {
-        const uint16_t *sx = (pl ? a.xl : a.xh) + (long)p * NPAD * CIN;
-        for (int c = tid; c < NPAD * NCX; c += 512)
-          *reinterpret_cast<uint4 *>(xs + pl * XPL + px_off<CIN>(c / NCX, c % NCX)) =
-              *reinterpret_cast<const uint4 *>(sx + (long)c * 8);
-        const uint16_t *sy = (pl ? a.dyl : a.dyh) + (long)p * NPAD * COUT;
-        for (int c = tid; c < NPAD * NCY; c += 512)
-          *reinterpret_cast<uint4 *>(ys + pl * YPL + px_off<COUT>(c / NCY, c % NCY)) =
-              *reinterpret_cast<const uint4 *>(sy + (long)c * 8);
+      PlaneLoad<CIN, 512> xh_, xl_;
+      PlaneLoad<COUT, 512> yh_, yl_;
+      // plane by plane: with every CU in its load phase at once, more bytes in flight per CU only
+      // lengthens the HBM queues (measured: all-planes-first was 1.4x slower here)
+      xh_.load(a.xh + (long)p * NPAD * CIN, tid);
+      xh_.store(xs, tid);
+      yh_.load(a.dyh + (long)p * NPAD * COUT, tid);
+      yh_.store(ys, tid);
+      if (SPLIT == 3) {
+        xl_.load(a.xl + (long)p * NPAD * CIN, tid);
+        xl_.store(xs + XPL, tid);
+        yl_.load(a.dyl + (long)p * NPAD * COUT, tid);
+        yl_.store(ys + YPL, tid);
       }
     }
     __syncthreads();
-    // bias gradient: tap row 0 only; thread t < COUT sums column t over the 144 pixels (halo is zero)
-    if (dy == 0 && tid < COUT) {
+    // bias gradient: every thread takes channel tid % COUT and every (512/COUT * 3)-th interior pixel
+    // (the three tap-row workgroups of a patch slice share the pixels, so the extra work is balanced)
+    {
+      constexpr int PARTS = 512 / COUT;
+      const int c = tid % COUT, part = tid / COUT;
       float s = 0.f;
-      for (int pp = 0; pp < NPAD; ++pp) {
-        const int o = px_off<COUT>(pp, tid >> 3) + 2 * (tid & 7);
+      for (int i = part * 3 + dy; i < NPIX; i += PARTS * 3) {
+        const int o = px_off<COUT>((i / IMG_W + 1) * PAD_W + (i % IMG_W + 1), c >> 3) + 2 * (c & 7);
         s += bf2f(*reinterpret_cast<const uint16_t *>(ys + o));
         if (SPLIT == 3) s += bf2f(*reinterpret_cast<const uint16_t *>(ys + YPL + o));
       }
       dbsum += s;
     }
-    // reduction over the padded pixel grid: k = padded pixel index of dY (halo rows are zero, so
-    // they add nothing); the matching X pixel is k + (dy-1)*12 + (dx-1), clamped into the plane
-    // (a clamped row only ever meets a zero dY row).
-    constexpr int KSTEPS = (NPAD + 31) / 32;  // 5 (160 rows, rows >= 144 clamp onto zero halo rows)
+    // reduction over the 100 interior pixels (k = interior index i, 4 k-steps of 32; rows i >= 100
+    // read halo pixel 0 of dY, which is zero, so they add nothing; their X row is pixel 13 so that
+    // every tap shift stays inside the plane).
+    // dY pixel: pp = (i/10 + 1)*12 + i%10 + 1 ; matching X pixel for tap (dy,dx): pp + (dy-1)*12 + (dx-1).
+    constexpr int KSTEPS = (NPIX + 31) / 32;
+    const int t16 = lane & 15, q = t16 >> 2, pq = t16 & 3;
+    const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
 #pragma unroll 1
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      auto ypix = [&](int q) { const int k = 32 * ks + 8 * g + q; return k < NPAD ? k : 0; };  // pixel 0 is halo (zero)
+      const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
+      const int py_lo = i_lo < NPIX ? (i_lo / IMG_W + 1) * PAD_W + (i_lo % IMG_W + 1) : 0;
+      const int py_hi = i_hi < NPIX ? (i_hi / IMG_W + 1) * PAD_W + (i_hi % IMG_W + 1) : 0;
+      const int px_lo = (i_lo < NPIX ? py_lo : PAD_W + 1) + (dy - 1) * PAD_W - 1;  // tap dx = 0
+      const int px_hi = (i_hi < NPIX ? py_hi : PAD_W + 1) + (dy - 1) * PAD_W - 1;
+      const uint32_t ya_lo = ys_a + py_lo * row_stride<COUT>() + lane_col + 2 * co0;
+      const uint32_t ya_hi = ys_a + py_hi * row_stride<COUT>() + lane_col + 2 * co0;
+      const uint32_t xa_lo = xs_a + px_lo * row_stride<CIN>() + lane_col + 32 * nt0;
+      const uint32_t xa_hi = xs_a + px_hi * row_stride<CIN>() + lane_col + 32 * nt0;
       bf8 ah[MTW], al[MTW];
-#pragma unroll
-      for (int i = 0; i < MTW; ++i) {
-        ah[i] = tr_frag<COUT>(ys_a, co0 + 16 * i, lane, ypix);
-        if (SPLIT == 3) al[i] = tr_frag<COUT>(ys_a + YPL, co0 + 16 * i, lane, ypix);
-      }
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int sh = (dy - 1) * PAD_W + (dx - 1);
-        auto xpix = [&](int q) {
-          int k = 32 * ks + 8 * g + q;
-          if (k >= NPAD) k = 0;
-          const int s = k + sh;
-          return s < 0 ? 0 : (s >= NPAD ? NPAD - 1 : s);
+      ah[0] = tr_frag<0>(ya_lo, ya_hi);
+      if (SPLIT == 3) al[0] = tr_frag<YPL>(ya_lo, ya_hi);
+      static_assert(MTW == 1, "one co tile per wave");
+      auto taps = [&](auto DXC) {
+        constexpr int dx = decltype(DXC)::value;
+        constexpr int XO = dx * row_stride<CIN>();  // tap shift = dx pixels to the right
+        bf8 bh[NTW], bl[NTW];
+        auto rd = [&](auto JC) {
+          constexpr int j = decltype(JC)::value;
+          if constexpr (j < NTW) {
+            bh[j] = tr_frag<XO + 32 * j>(xa_lo, xa_hi);
+            if (SPLIT == 3) bl[j] = tr_frag<XPL + XO + 32 * j>(xa_lo, xa_hi);
+          }
         };
+        rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{});
+        rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+        rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{});
+        rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          const bf8 bh = tr_frag<CIN>(xs_a, 16 * (nt0 + j), lane, xpix);
-          bf8 bl;
-          if (SPLIT == 3) bl = tr_frag<CIN>(xs_a + XPL, 16 * (nt0 + j), lane, xpix);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < MTW; ++i) {
-            if (SPLIT == 3) {
-              acc[dx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[dx][i][j], 0, 0, 0);
-              acc[dx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[dx][i][j], 0, 0, 0);
-            }
-            acc[dx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[dx][i][j], 0, 0, 0);
+          if (SPLIT == 3) {
+            acc[dx][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh[j], acc[dx][0][j], 0, 0, 0);
+            acc[dx][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl[j], acc[dx][0][j], 0, 0, 0);
           }
+          acc[dx][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh[j], acc[dx][0][j], 0, 0, 0);
         }
-      }
+      };
+      taps(std::integral_constant<int, 0>{});
+      taps(std::integral_constant<int, 1>{});
+      taps(std::integral_constant<int, 2>{});
     }
   }
 
-  // partial sums -> global gradient.  acc[dx][i][j][r] = dW[co0 + 16 i + 4 g + r][ci 16 (nt0+j) + lane&15][dy][dx]
+  // partial sums of this patch slice -> workspace (plain stores; a second kernel adds the slices
+  // in a fixed order, so gradients are bitwise reproducible and no float atomics are needed).
+  // acc[dx][i][j][r] = dW[co0 + 16 i + 4 g + r][ci 16 (nt0+j) + lane&15][dy][dx]
+  float *dwp = a.dw_part + (long)blockIdx.y * COUT * CIN * 9;
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -351,9 +427,28 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + 16 * i + 4 * g + r, ci = 16 * (nt0 + j) + (lane & 15);
-          atomicAdd(a.dw + (((long)co * CIN + ci) * 3 + dy) * 3 + dx, acc[dx][i][j][r]);
+          dwp[(((long)co * CIN + ci) * 3 + dy) * 3 + dx] = acc[dx][i][j][r];
         }
-  if (dy == 0 && tid < COUT) atomicAdd(a.db + tid, dbsum);
+  // bias partials: reduce the 512/COUT pixel parts of each channel through LDS
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(lds);
+  red[tid] = dbsum;
+  __syncthreads();
+  if (tid < COUT) {
+    float s = 0.f;
+    for (int part = 0; part < 512 / COUT; ++part) s += red[part * COUT + tid];
+    a.db_part[((long)blockIdx.y * 3 + dy) * COUT + tid] = s;
+  }
+}
+
+// out[e] = sum over slices of part[s][e]   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void slice_sum_kernel(const float *__restrict__ part, int nslice, long n,
+                                                        float *__restrict__ out) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += part[(long)k * n + e];
+    out[e] = s;
+  }
 }
 
 // ---- small helpers --------------------------------------------------------------------------------
@@ -405,7 +500,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ 
 template <int SPLIT, int CIN, int COUT, int MODE>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * NPAD * CMAX * 2;
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * plane_bytes<CMAX>();
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE>,
@@ -420,8 +515,8 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
 }
 
 template <int SPLIT, int CIN, int COUT>
-int launch_wgrad(const WgradArgs &a, hipStream_t s) {
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * NPAD * (CIN + COUT) * 2;
+int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (plane_bytes<CIN>() + plane_bytes<COUT>());
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT>,
@@ -431,7 +526,6 @@ int launch_wgrad(const WgradArgs &a, hipStream_t s) {
     }
     attr = true;
   }
-  const int nblk = (a.P + a.patches_per_block - 1) / a.patches_per_block;
   hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT>), dim3(3, nblk), dim3(512), lds, s, a);
   return check_launch();
 }
@@ -497,25 +591,42 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
   return CRW_EINVAL;
 }
 
+static int wgrad_slices(int P, int cin, int cout, int split) {
+  const size_t lds = (size_t)(split == 3 ? 2 : 1) * NPAD * ((size_t)(cin + cout) * 2 + 32);
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;  // workgroups of 512 threads per CU
+  int n = 256 * per_cu / 3;                     // three tap-row workgroups per slice
+  return n > P ? P : n;
+}
+
+size_t crw_enc_wgrad_ws_bytes(int P, int cin, int cout, int split) {
+  if (P < 1 || cin < 1 || cout < 1) return 0;
+  return (size_t)wgrad_slices(P, cin, cout, split) * ((size_t)cout * cin * 9 + 3 * (size_t)cout) * sizeof(float);
+}
+
 int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
-                          const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, crw_stream_t stream) {
+                          const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, void *ws, size_t ws_bytes,
+                          crw_stream_t stream) {
   clear_stale_error();
-  if (!dy_hi || !x_hi || !dw || !db || P < 1 || (split != 1 && split != 3)) return CRW_EINVAL;
+  if (!dy_hi || !x_hi || !dw || !db || !ws || P < 1 || (split != 1 && split != 3)) return CRW_EINVAL;
   if (split == 3 && (!dy_lo || !x_lo)) return CRW_EINVAL;
+  if (ws_bytes < crw_enc_wgrad_ws_bytes(P, cin, cout, split)) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dw, 0, sizeof(float) * cout * cin * 9, s) != hipSuccess) return CRW_EHIP;
-  if (hipMemsetAsync(db, 0, sizeof(float) * cout, s) != hipSuccess) return CRW_EHIP;
-  // ~2 blocks per tap row per CU worth of slices
-  int ppb = (P + 511) / 512;
-  if (ppb < 1) ppb = 1;
-  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dw, db, P, ppb};
+  const int nslice = wgrad_slices(P, cin, cout, split);
+  const int ppb = (P + nslice - 1) / nslice;
+  float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dw_part, db_part, P, ppb};
+  int st = CRW_EINVAL;
 #define CRW_WG_CASE(CI, CO)                                                                  \
-  if (cin == CI && cout == CO) return split == 3 ? launch_wgrad<3, CI, CO>(a, s) : launch_wgrad<1, CI, CO>(a, s);
+  if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);
   CRW_WG_CASE(32, 64)
   CRW_WG_CASE(64, 128)
   CRW_WG_CASE(128, 128)
 #undef CRW_WG_CASE
-  return CRW_EINVAL;
+  if (st != CRW_OK) return st;
+  const long nw = (long)cout * cin * 9;
+  hipLaunchKernelGGL(slice_sum_kernel, dim3(ew_grid(nw)), dim3(256), 0, s, dw_part, nslice, nw, dw);
+  hipLaunchKernelGGL(slice_sum_kernel, dim3(1), dim3(256), 0, s, db_part, nslice * 3, (long)cout, db);
+  return check_launch();
 }
 
 }  // extern "C"

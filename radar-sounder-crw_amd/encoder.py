@@ -48,7 +48,8 @@ class _HipConv345(torch.autograd.Function):
         _, _, dx, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *ctx.bwd_w[0], 32, planes=False, f32=True)
         ctx.planes = None
         P = dx.shape[0]
-        return dx.view(P, 10, 10, 32).permute(0, 3, 1, 2), dw3, db3, dw4, db4, dw5, db5, None
+        dx = dx.view(P, 10, 10, 32).permute(0, 3, 1, 2).contiguous()  # NCHW like the forward input
+        return dx, dw3, db3, dw4, db4, dw5, db5, None
 
 # (name, out_channels, kernel, followed by 2x2/stride-1 max-pool?)
 _CNN_STACK = (("1", 8, 5, True), ("2", 32, 5, True), ("3", 64, 3, False), ("4", 128, 3, False), ("5", 128, 3, False))
