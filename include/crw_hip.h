@@ -113,8 +113,8 @@ int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int
                  int beta, crw_stream_t stream);
 
 /* encoder: hand-written 3x3 convolutions of CNN (conv3/conv4/conv5, src/encoder.py:26-35) --------- */
-/* Activations are channels-last bf16 planes [P][12*12][C] with a one-pixel zero halo ("hi" plane and,
- * for split = 3, a "lo" plane: x = hi + lo to fp32 accuracy).  10x10 patches (16x16 input patches).
+/* Activations are channels-last bf16 planes [P][100][C] ("hi" plane and, for split = 3, a "lo"
+ * plane: x = hi + lo to ~1e-5 relative).  10x10 feature maps (16x16 input patches).
  * fp32 conv weight [cout][cin][3][3] -> forward planes [9][cout][cin] and backward-data planes
  * (taps flipped, [9][cin][cout]); lo planes may be NULL together (plain bf16). */
 int crw_enc_pack_weights(const float *w, int cout, int cin, uint16_t *fwd_hi, uint16_t *fwd_lo,
@@ -123,16 +123,16 @@ int crw_enc_pack_weights(const float *w, int cout, int cin, uint16_t *fwd_hi, ui
 int crw_enc_pack_input(const float *x, int P, int C, uint16_t *x_hi, uint16_t *x_lo, crw_stream_t stream);
 /* mode 0: y = relu(conv3x3(x, w) + bias), optional gap[P][cout] = mean over pixels (AdaptiveAvgPool2d(1));
  * mode 1: backward-data, y = conv3x3(x = dY, w = backward planes), zeroed where mask_hi (the forward
- *         activation of the layer below, [P][144][cout]) is 0; bias ignored.
+ *         activation of the layer below, [P][100][cout]) is 0; bias ignored.
  * (cin, cout) in {(32,64),(64,128),(128,128),(128,64),(64,32)}.  Outputs: planes y_hi/y_lo and/or
  * y_f32 [P][100][cout] (unpadded fp32). */
 int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
                     const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi,
                     uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, crw_stream_t stream);
-/* dY planes [P][144][C] = dgap[P][C] / 100 where y_hi != 0 (backward of ReLU + global average pool) */
+/* dY planes [P][100][C] = dgap[P][C] / 100 where y_hi != 0 (backward of ReLU + global average pool) */
 int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
                     crw_stream_t stream);
-/* dw [cout][cin][3][3], db [cout] (fp32, overwritten) from dY planes [P][144][cout] and x planes [P][144][cin].
+/* dw [cout][cin][3][3], db [cout] (fp32, overwritten) from dY planes [P][100][cout] and x planes [P][100][cin].
  * Per-slice partial sums go to `ws` (crw_enc_wgrad_ws_bytes) and are added in a fixed order:
  * no float atomics, bitwise reproducible. */
 size_t crw_enc_wgrad_ws_bytes(int P, int cin, int cout, int split);

@@ -211,11 +211,11 @@ def enc_pack_weights(w, split):
 
 
 def enc_pack_input(x, split):
-    """fp32 NCHW [P,C,10,10] -> channels-last planes [P,144,C] with zero halo."""
+    """fp32 NCHW [P,C,10,10] -> channels-last planes [P,100,C]."""
     P, C, H, W = x.shape
     if (H, W) != (10, 10):
         raise RuntimeError(f"the HIP conv stack handles 10x10 feature maps (16x16 patches), got {H}x{W}")
-    xh = torch.empty(P, 144, C, dtype=_BF, device=x.device)
+    xh = torch.empty(P, 100, C, dtype=_BF, device=x.device)
     xl = torch.empty_like(xh) if split == 3 else None
     _check(lib().crw_enc_pack_input(_dev(x.contiguous(), "x"), P, C, _bf(xh, "xh"), _bf(xl, "xl"), _stream()),
            "crw_enc_pack_input")
@@ -226,7 +226,7 @@ def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=
     """mode 0: relu(conv + bias) ; mode 1: backward-data with optional ReLU mask.  -> (yh, yl, yf, gap)"""
     P, _, cin = xh.shape
     dev = xh.device
-    yh = torch.empty(P, 144, cout, dtype=_BF, device=dev) if planes else None
+    yh = torch.empty(P, 100, cout, dtype=_BF, device=dev) if planes else None
     yl = torch.empty_like(yh) if (planes and split == 3) else None
     yf = torch.empty(P, 100, cout, dtype=torch.float32, device=dev) if f32 else None
     gp = torch.empty(P, cout, dtype=torch.float32, device=dev) if gap else None

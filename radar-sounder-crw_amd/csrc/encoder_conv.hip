@@ -8,8 +8,9 @@
 //              Ah*Bh + Ah*Bl + Al*Bh -> fp32-grade results (parity path);
 //   SPLIT = 1: plain bf16 operands (throughput path).
 //
-// Layout: activations are channels-last with a one-pixel zero halo, [P][12*12][C] bf16 planes
-// (hi and lo), so a tap is a constant pixel offset and no border predication exists.  One
+// Layout: activations live in HBM as compact channels-last bf16 planes [P][100][C] (hi and lo).
+// In LDS a patch is a 12x12 image with a one-pixel zero halo (zeroed once, never loaded), so a tap
+// is a constant pixel offset and no border predication exists.  One
 // workgroup = one patch: the patch (all channels, both planes) is loaded into LDS once and serves
 // all 9 taps x all output channels; rows are XOR-swizzled by pixel so the 16 pixels of an MFMA row
 // tile hit distinct banks.  Waves split the output channels; weight fragments ([tap][co][ci], 16 B
@@ -54,39 +55,57 @@ __device__ inline int px_off(int pp, int chunk) { return pp * row_stride<C>() + 
 // global plane [144][C] (one patch) -> LDS plane.  load() only issues the global loads, store()
 // writes LDS: callers issue the loads of ALL planes first, so one HBM round trip covers them all
 // (load-wait-store per plane, or per 16 bytes, exposes one round trip each).
+__device__ inline int interior_pp(int i) { return (i / IMG_W + 1) * PAD_W + (i % IMG_W + 1); }
+
 template <int C, int NTHREADS>
 struct PlaneLoad {
-  static constexpr int NCH = C / 8, TOTAL = NPAD * NCH, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  static constexpr int NCH = C / 8, TOTAL = NPIX * NCH, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
   uint4 v[ITER];
-  __device__ inline void load(const uint16_t *__restrict__ src, int tid) {
+  __device__ inline void load(const uint16_t *__restrict__ src, int tid) {  // src: [100][C] of one patch
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int c = tid + i * NTHREADS;
       if (TOTAL % NTHREADS == 0 || c < TOTAL) v[i] = *reinterpret_cast<const uint4 *>(src + (long)c * 8);
     }
   }
-  __device__ inline void store(char *dst, int tid) const {
+  __device__ inline void store(char *dst, int tid) const {  // into the interior of the padded LDS image
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int c = tid + i * NTHREADS;
-      if (TOTAL % NTHREADS == 0 || c < TOTAL) *reinterpret_cast<uint4 *>(dst + px_off<C>(c / NCH, c % NCH)) = v[i];
+      if (TOTAL % NTHREADS == 0 || c < TOTAL)
+        *reinterpret_cast<uint4 *>(dst + px_off<C>(interior_pp(c / NCH), c % NCH)) = v[i];
     }
   }
 };
 
+// zero the 44 halo pixels of an LDS plane
+template <int C, int NTHREADS>
+__device__ inline void zero_halo(char *plane, int tid) {
+  constexpr int NCH = C / 8;
+  for (int c = tid; c < 44 * NCH; c += NTHREADS) {
+    const int h = c / NCH, ch = c % NCH;
+    // halo pixels in order: top row (12), bottom row (12), then left/right of the 10 middle rows
+    const int pp = h < 12 ? h : (h < 24 ? 11 * PAD_W + (h - 12) : (1 + (h - 24) / 2) * PAD_W + ((h - 24) & 1) * 11);
+    *reinterpret_cast<uint4 *>(plane + px_off<C>(pp, ch)) = uint4{0, 0, 0, 0};
+  }
+}
+
 struct ConvArgs {
-  const uint16_t *xh, *xl;   // [P][144][CIN] input planes (zero halo)
+  const uint16_t *xh, *xl;   // [P][100][CIN] input planes
   const uint16_t *wh, *wl;   // [9][COUT][CIN] weights (already flipped/transposed for backward-data)
   const float *bias;         // [COUT] (MODE 0) or null
-  const uint16_t *maskh;     // [P][144][COUT]: output is zeroed where this plane is 0 (MODE 1) or null
-  uint16_t *yh, *yl;         // [P][144][COUT] output planes (zero halo written) or null
+  const uint16_t *maskh;     // [P][100][COUT]: output is zeroed where this plane is 0 (MODE 1) or null
+  uint16_t *yh, *yl;         // [P][100][COUT] output planes or null
   float *yf;                 // optional fp32 output [P][100][COUT]
   float *gap;                // optional [P][COUT]: mean over the 100 pixels (MODE 0)
   int P;
 };
 
-template <int SPLIT, int CIN, int COUT, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+// PPW patches per workgroup (PPW x 4 waves): the wave groups run the same weight stream on different
+// patches side by side, so their identical weight-fragment requests meet in the CU's L1 / miss
+// queue and the L2 sees them once -- the kernel is bound by weight bytes per CU, not by MFMA issue.
+template <int SPLIT, int CIN, int COUT, int MODE, int PPW>
+__global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
   constexpr int PLANE = plane_bytes<CMAX>();  // bytes per LDS plane (input image, later output staging)
@@ -95,17 +114,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   constexpr int NTW = COUT / 16 / WN;                   // 16-wide column tiles per wave
   constexpr int MTW = (MT + WM - 1) / WM;               // row tiles per wave (tile wm + WM*k)
   constexpr int KCH = CIN / 32;                         // 32-deep k-steps per tap
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
 
-  const int p = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = threadIdx.x / 256;            // which patch of this workgroup
+  int p = blockIdx.x * PPW + half;
+  const bool live = p < a.P;                     // a tail workgroup may hold a spare wave group:
+  if (!live) p = a.P - 1;                        // it recomputes the last patch and writes nothing
+  char *lds = lds_all + half * (NPL * PLANE);
+  const int tid = threadIdx.x % 256, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
 
-  // ---- patch -> LDS (swizzled) ---------------------------------------------------------------
+  // ---- patch -> LDS ------------------------------------------------------------------------------
   {
     PlaneLoad<CIN, 256> lh, ll;
-    lh.load(a.xh + (long)p * NPAD * CIN, tid);
-    if (SPLIT == 3) ll.load(a.xl + (long)p * NPAD * CIN, tid);
+    lh.load(a.xh + (long)p * NPIX * CIN, tid);
+    if (SPLIT == 3) ll.load(a.xl + (long)p * NPIX * CIN, tid);
+    zero_halo<CIN, 256>(lds, tid);
+    if (SPLIT == 3) zero_halo<CIN, 256>(lds + PLANE, tid);
     lh.store(lds, tid);
     if (SPLIT == 3) ll.store(lds + PLANE, tid);
   }
@@ -188,12 +213,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     bias_r[j] = (MODE == 0 && a.bias) ? a.bias[co_w + 16 * j + r16] : 0.f;
   }
   __syncthreads();  // every wave is done reading the input image: reuse LDS as the output staging
-  if (a.yh) {       // zero the staging planes (the halo stays zero)
-    constexpr int OUTB = plane_bytes<COUT>();
-    for (int pl = 0; pl < NPL; ++pl)
-      for (int c = tid; c < OUTB / 16; c += 256) *reinterpret_cast<uint4 *>(lds + pl * PLANE + 16 * c) = uint4{0, 0, 0, 0};
-    __syncthreads();
-  }
 #pragma unroll
   for (int k = 0; k < MTW; ++k)
 #pragma unroll
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             v = fmaxf(v + bias_r[j], 0.f);
             gsum[j] += v;
           }
-          if (a.yf) a.yf[((long)p * NPIX + i) * COUT + co] = v;
+          if (a.yf && live) a.yf[((long)p * NPIX + i) * COUT + co] = v;
           if (a.yh) {
             const uint16_t h = f2bf(v);
             *reinterpret_cast<uint16_t *>(lds + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = h;
@@ -225,15 +244,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       float s = gsum[j];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
-      if (g == 0) a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
+      if (g == 0 && live) a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
     }
   }
   if (a.yh) {
     __syncthreads();
     // staged tile -> global in whole 16-byte chunks; the ReLU mask of the layer below (MODE 1) is
     // applied here, 8 channels at a time, from the matching chunk of its activation plane
-    constexpr int NCH = COUT / 8, TOTAL = NPAD * NCH, ITER = (TOTAL + 255) / 256;
-    const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (long)p * NPAD * COUT : nullptr;
+    constexpr int NCH = COUT / 8, TOTAL = NPIX * NCH, ITER = (TOTAL + 255) / 256;
+    const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (long)p * NPIX * COUT : nullptr;
     uint4 mv[ITER];
     if (mk) {
 #pragma unroll
@@ -243,13 +262,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       }
     }
     for (int pl = 0; pl < NPL; ++pl) {
-      uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPAD * COUT;
+      uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPIX * COUT;
       const char *src = lds + pl * PLANE;
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int c = tid + it * 256;
         if (c < TOTAL) {
-          uint4 v = *reinterpret_cast<const uint4 *>(src + px_off<COUT>(c / NCH, c % NCH));
+          uint4 v = *reinterpret_cast<const uint4 *>(src + px_off<COUT>(interior_pp(c / NCH), c % NCH));
           if (mk) {  // keep a bf16 lane only where the mask lane is non-zero
             const uint32_t m[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
             uint32_t o[4] = {v.x, v.y, v.z, v.w};
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             }
             v = uint4{o[0], o[1], o[2], o[3]};
           }
-          *reinterpret_cast<uint4 *>(dst + (long)c * 8) = v;
+          if (live) *reinterpret_cast<uint4 *>(dst + (long)c * 8) = v;
         }
       }
     }
@@ -271,8 +290,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 // weight gradient.  grid = (3 tap rows, NG patch slices); 512 threads = 8 waves, wave w owns output
 // channels [w*COUT/8, +COUT/8) x all CIN x the 3 taps of its row.
 struct WgradArgs {
-  const uint16_t *dyh, *dyl;  // [P][144][COUT] masked output gradient planes (zero halo)
-  const uint16_t *xh, *xl;    // [P][144][CIN] layer input planes (zero halo)
+  const uint16_t *dyh, *dyl;  // [P][100][COUT] masked output gradient planes
+  const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
   float *dw_part;             // [nslice][COUT][CIN][3][3] fp32 partial sums (every element written)
   float *db_part;             // [nslice][3][COUT] fp32 partial sums
   int P, patches_per_block;
@@ -328,6 +347,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int p_end = min(a.P, p_begin + a.patches_per_block);
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
 
+  // the halo of the LDS images is zeroed once; patch loads only ever touch the interior
+  zero_halo<CIN, 512>(xs, tid);
+  zero_halo<COUT, 512>(ys, tid);
+  if (SPLIT == 3) {
+    zero_halo<CIN, 512>(xs + XPL, tid);
+    zero_halo<COUT, 512>(ys + YPL, tid);
+  }
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();  // previous patch fully consumed
     {
@@ -335,14 +361,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
       PlaneLoad<COUT, 512> yh_, yl_;
       // plane by plane: with every CU in its load phase at once, more bytes in flight per CU only
       // lengthens the HBM queues (measured: all-planes-first was 1.4x slower here)
-      xh_.load(a.xh + (long)p * NPAD * CIN, tid);
+      xh_.load(a.xh + (long)p * NPIX * CIN, tid);
       xh_.store(xs, tid);
-      yh_.load(a.dyh + (long)p * NPAD * COUT, tid);
+      yh_.load(a.dyh + (long)p * NPIX * COUT, tid);
       yh_.store(ys, tid);
       if (SPLIT == 3) {
-        xl_.load(a.xl + (long)p * NPAD * CIN, tid);
+        xl_.load(a.xl + (long)p * NPIX * CIN, tid);
         xl_.store(xs + XPL, tid);
-        yl_.load(a.dyl + (long)p * NPAD * COUT, tid);
+        yl_.load(a.dyl + (long)p * NPIX * COUT, tid);
         yl_.store(ys + YPL, tid);
       }
     }
@@ -466,31 +492,29 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
   }
 }
 
-// fp32 NCHW [P][C][10][10] -> planes [P][144][C] with zero halo
+// fp32 NCHW [P][C][10][10] -> channels-last planes [P][100][C]
 __global__ __launch_bounds__(256) void pack_input_kernel(const float *__restrict__ x, int P, int C, uint16_t *xh,
                                                          uint16_t *xl) {
-  const long n = (long)P * NPAD * C;
+  const long n = (long)P * NPIX * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-    const int c = e % C, pp = (e / C) % NPAD;
-    const long p = e / ((long)C * NPAD);
-    const int yy = pp / PAD_W - 1, xx = pp % PAD_W - 1;
-    float v = 0.f;
-    if (yy >= 0 && yy < IMG_W && xx >= 0 && xx < IMG_W) v = x[((p * C + c) * IMG_W + yy) * IMG_W + xx];
+    const int c = e % C, i = (e / C) % NPIX;
+    const long p = e / ((long)C * NPIX);
+    const float v = x[(p * C + c) * NPIX + i];
     const uint16_t h = f2bf(v);
     xh[e] = h;
     if (xl) xl[e] = f2bf(v - bf2f(h));
   }
 }
 
-// dY[p][pp][c] = dgap[p][c] / 100 where the forward output was positive (ReLU) and pp is interior
+// dY[p][i][c] = dgap[p][c] / 100 where the forward output was positive (ReLU)
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ dgap, const uint16_t *__restrict__ yh,
                                                       int P, int C, uint16_t *dh, uint16_t *dl) {
-  const long n = (long)P * NPAD * C;
+  const long n = (long)P * NPIX * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     const int c = e % C;
-    const long p = e / ((long)C * NPAD);
+    const long p = e / ((long)C * NPIX);
     float v = 0.f;
-    if ((yh[e] & 0x7fff) != 0) v = dgap[p * C + c] * (1.0f / NPIX);  // halo of yh is zero
+    if ((yh[e] & 0x7fff) != 0) v = dgap[p * C + c] * (1.0f / NPIX);
     const uint16_t h = f2bf(v);
     dh[e] = h;
     if (dl) dl[e] = f2bf(v - bf2f(h));
@@ -500,17 +524,19 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ 
 template <int SPLIT, int CIN, int COUT, int MODE>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * plane_bytes<CMAX>();
+  constexpr int PPW = 1;  // 2 (one 512-thread workgroup, two patches) measured 15-20 % slower than two independent workgroups
+  const size_t lds = (size_t)PPW * (SPLIT == 3 ? 2 : 1) * plane_bytes<CMAX>();
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE>,
+    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE>), dim3(a.P), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256 * PPW), lds,
+                     s, a);
   return check_launch();
 }
 
@@ -554,7 +580,7 @@ int crw_enc_pack_weights(const float *w, int cout, int cin, uint16_t *fwd_hi, ui
 int crw_enc_pack_input(const float *x, int P, int C, uint16_t *xh, uint16_t *xl, crw_stream_t stream) {
   clear_stale_error();
   if (!x || !xh || P < 1 || C < 8 || C % 8) return CRW_EINVAL;
-  hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((long)P * NPAD * C)), dim3(256), 0, (hipStream_t)stream, x, P, C,
+  hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((long)P * NPIX * C)), dim3(256), 0, (hipStream_t)stream, x, P, C,
                      xh, xl);
   return check_launch();
 }
@@ -563,7 +589,7 @@ int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint1
                     crw_stream_t stream) {
   clear_stale_error();
   if (!dgap || !y_hi || !dy_hi || P < 1 || C < 1) return CRW_EINVAL;
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid((long)P * NPAD * C)), dim3(256), 0, (hipStream_t)stream, dgap, y_hi, P,
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid((long)P * NPIX * C)), dim3(256), 0, (hipStream_t)stream, dgap, y_hi, P,
                      C, dy_hi, dy_lo);
   return check_launch();
 }

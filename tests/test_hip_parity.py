@@ -173,11 +173,9 @@ def test_full_model_matches_reference(hip, name, wname, convs):
 
 
 def _to_planes_ref(t):
-    """fp32 NCHW [P,C,10,10] -> fp32 channels-last padded [P,144,C] (what the planes represent)."""
+    """fp32 NCHW [P,C,10,10] -> fp32 channels-last [P,100,C] (what the bf16 planes represent)."""
     P, C = t.shape[:2]
-    out = torch.zeros(P, 12, 12, C, dtype=t.dtype)
-    out[:, 1:11, 1:11] = t.permute(0, 2, 3, 1)
-    return out.reshape(P, 144, C)
+    return t.permute(0, 2, 3, 1).reshape(P, 100, C).contiguous()
 
 
 def _planes_value(h, l):
@@ -207,7 +205,7 @@ def test_encoder_conv_kernels_match_torch(hip, cin, cout, split):
         xp = _to_planes_ref(x).cuda()
         xh = xp.bfloat16()
         xl = (xp - xh.float()).bfloat16() if split == 3 else None
-    xq = _planes_value(xh, xl).cpu().double().reshape(P, 12, 12, cin)[:, 1:11, 1:11].permute(0, 3, 1, 2)
+    xq = _planes_value(xh, xl).cpu().double().reshape(P, 10, 10, cin).permute(0, 3, 1, 2)
     wq = w.cuda().bfloat16().float().cpu().double() if split == 1 else w.double()
     y_ref = TF.relu(TF.conv2d(xq, wq, b.double(), padding=1))
     yh, yl, yf, gap = hip.enc_conv3x3(0, split, xh, xl, fh, fl, cout, bias=b.cuda(), f32=True, gap=(cout == 128))
@@ -220,7 +218,7 @@ def test_encoder_conv_kernels_match_torch(hip, cin, cout, split):
     dyp = _to_planes_ref(dy).cuda()
     dyh = dyp.bfloat16()
     dyl = (dyp - dyh.float()).bfloat16() if split == 3 else None
-    dyq = _planes_value(dyh, dyl).cpu().double().reshape(P, 12, 12, cout)[:, 1:11, 1:11].permute(0, 3, 1, 2)
+    dyq = _planes_value(dyh, dyl).cpu().double().reshape(P, 10, 10, cout).permute(0, 3, 1, 2)
     dx_ref = TF.conv_transpose2d(dyq, wq, padding=1)
     maskp = _to_planes_ref(TF.relu(x)).cuda().bfloat16()
     _, _, dxf, _ = hip.enc_conv3x3(1, split, dyh, dyl, bh, bl, cin, planes=False, f32=True)
