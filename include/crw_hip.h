@@ -125,20 +125,25 @@ int crw_enc_pack_input(const float *x, int P, int C, uint16_t *x_hi, uint16_t *x
  * mode 1: backward-data, y = conv3x3(x = dY, w = backward planes), zeroed where mask_hi (the forward
  *         activation of the layer below, [P][100][cout]) is 0; bias ignored.
  * (cin, cout) in {(32,64),(64,128),(128,128),(128,64),(64,32)}.  Outputs: planes y_hi/y_lo and/or
- * y_f32 [P][100][cout] (unpadded fp32). */
+ * y_f32 [P][100][cout] (fp32); y_lo may be NULL when only the hi plane of the result is needed.
+ * dgap (mode 1 only, may be NULL): fused ReLU + global-average-pool backward -- the input gradient
+ * is dgap[P][cin] / 100 where x_hi (then the FORWARD activation plane of that layer) is non-zero;
+ * x_lo is ignored. */
 int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
                     const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi,
-                    uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, crw_stream_t stream);
+                    uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, const float *dgap,
+                    crw_stream_t stream);
 /* dY planes [P][100][C] = dgap[P][C] / 100 where y_hi != 0 (backward of ReLU + global average pool) */
 int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
                     crw_stream_t stream);
 /* dw [cout][cin][3][3], db [cout] (fp32, overwritten) from dY planes [P][100][cout] and x planes [P][100][cin].
  * Per-slice partial sums go to `ws` (crw_enc_wgrad_ws_bytes) and are added in a fixed order:
- * no float atomics, bitwise reproducible. */
+ * no float atomics, bitwise reproducible.  dgap (may be NULL): as in crw_enc_conv3x3, dY = dgap/100
+ * gated by dy_hi (= forward activation plane); dy_lo ignored. */
 size_t crw_enc_wgrad_ws_bytes(int P, int cin, int cout, int split);
 int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
-                          const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, void *ws,
-                          size_t ws_bytes, crw_stream_t stream);
+                          const uint16_t *x_hi, const uint16_t *x_lo, const float *dgap, float *dw, float *db,
+                          void *ws, size_t ws_bytes, crw_stream_t stream);
 
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous

@@ -38,10 +38,10 @@ SIGNATURES = {
     "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
     "crw_enc_pack_weights": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
-    "crw_enc_conv3x3": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_conv3x3": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p]),
     "crw_enc_wgrad_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
-    "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
+    "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -222,18 +222,20 @@ def enc_pack_input(x, split):
     return xh, xl
 
 
-def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=True, f32=False, gap=False):
-    """mode 0: relu(conv + bias) ; mode 1: backward-data with optional ReLU mask.  -> (yh, yl, yf, gap)"""
+def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=True, f32=False, gap=False,
+                dgap=None, lo_plane=True):
+    """mode 0: relu(conv + bias) ; mode 1: backward-data with optional ReLU mask.  -> (yh, yl, yf, gap).
+    dgap (mode 1): the input gradient is dgap/100 gated by xh (forward activation plane), xl ignored."""
     P, _, cin = xh.shape
     dev = xh.device
     yh = torch.empty(P, 100, cout, dtype=_BF, device=dev) if planes else None
-    yl = torch.empty_like(yh) if (planes and split == 3) else None
+    yl = torch.empty_like(yh) if (planes and split == 3 and lo_plane) else None
     yf = torch.empty(P, 100, cout, dtype=torch.float32, device=dev) if f32 else None
     gp = torch.empty(P, cout, dtype=torch.float32, device=dev) if gap else None
     _check(lib().crw_enc_conv3x3(mode, split, P, cin, cout, _bf(xh, "xh"), _bf(xl, "xl"), _bf(wh, "wh"), _bf(wl, "wl"),
                                  _dev(bias, "bias") if bias is not None else None, _bf(mask, "mask"), _bf(yh, "yh"),
                                  _bf(yl, "yl"), _dev(yf, "yf") if f32 else None, _dev(gp, "gap") if gap else None,
-                                 _stream()), "crw_enc_conv3x3")
+                                 _dev(dgap, "dgap") if dgap is not None else None, _stream()), "crw_enc_conv3x3")
     return yh, yl, yf, gp
 
 
@@ -246,7 +248,8 @@ def enc_gap_bwd(dgap, yh, split):
     return dh, dl
 
 
-def enc_wgrad(split, dyh, dyl, xh, xl):
+def enc_wgrad(split, dyh, dyl, xh, xl, dgap=None):
+    """dgap: dY = dgap/100 gated by dyh (forward activation plane) -- fused ReLU + GAP backward."""
     P, _, cout = dyh.shape
     cin = xh.shape[2]
     dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=xh.device)
@@ -254,6 +257,7 @@ def enc_wgrad(split, dyh, dyl, xh, xl):
     nbytes = lib().crw_enc_wgrad_ws_bytes(P, cin, cout, split)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xh.device)
     _check(lib().crw_enc_conv3x3_wgrad(split, P, cin, cout, _bf(dyh, "dyh"), _bf(dyl, "dyl"), _bf(xh, "xh"),
-                                       _bf(xl, "xl"), _dev(dw, "dw"), _dev(db, "db"), ctypes.c_void_p(ws.data_ptr()),
+                                       _bf(xl, "xl"), _dev(dgap, "dgap") if dgap is not None else None,
+                                       _dev(dw, "dw"), _dev(db, "db"), ctypes.c_void_p(ws.data_ptr()),
                                        nbytes, _stream()), "crw_enc_conv3x3_wgrad")
     return dw, db

@@ -78,6 +78,44 @@ struct PlaneLoad {
   }
 };
 
+// Fused ReLU5 + global-average-pool backward: the gradient planes of the last conv layer are never
+// materialised; dY[i][c] = dgap[c] / 100 where the forward activation y[i][c] (hi plane) is non-zero.
+// Loads the activation chunks, builds the hi/lo planes of dY directly in LDS.
+template <int C, int NTHREADS, int SPLIT>
+__device__ inline void gap_planes_to_lds(const uint16_t *__restrict__ yh, const float *__restrict__ dgap_row,
+                                         char *dst_hi, char *dst_lo, int tid) {
+  constexpr int NCH = C / 8, TOTAL = NPIX * NCH, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  uint4 v[ITER];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int c = tid + i * NTHREADS;
+    if (TOTAL % NTHREADS == 0 || c < TOTAL) v[i] = *reinterpret_cast<const uint4 *>(yh + (long)c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int c = tid + i * NTHREADS;
+    if (TOTAL % NTHREADS == 0 || c < TOTAL) {
+      const int ch = c % NCH;
+      const float4 g0 = *reinterpret_cast<const float4 *>(dgap_row + 8 * ch);
+      const float4 g1 = *reinterpret_cast<const float4 *>(dgap_row + 8 * ch + 4);
+      const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const uint32_t yw[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      uint32_t oh[4], ol[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float a0 = (yw[w] & 0x7fffu) ? gv[2 * w] * (1.0f / NPIX) : 0.f;
+        const float a1 = (yw[w] & 0x7fff0000u) ? gv[2 * w + 1] * (1.0f / NPIX) : 0.f;
+        const uint16_t h0 = f2bf(a0), h1 = f2bf(a1);
+        oh[w] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        ol[w] = (uint32_t)f2bf(a0 - bf2f(h0)) | ((uint32_t)f2bf(a1 - bf2f(h1)) << 16);
+      }
+      const int off = px_off<C>(interior_pp(c / NCH), ch);
+      *reinterpret_cast<uint4 *>(dst_hi + off) = uint4{oh[0], oh[1], oh[2], oh[3]};
+      if (SPLIT == 3) *reinterpret_cast<uint4 *>(dst_lo + off) = uint4{ol[0], ol[1], ol[2], ol[3]};
+    }
+  }
+}
+
 // zero the 44 halo pixels of an LDS plane
 template <int C, int NTHREADS>
 __device__ inline void zero_halo(char *plane, int tid) {
@@ -98,6 +136,8 @@ struct ConvArgs {
   uint16_t *yh, *yl;         // [P][100][COUT] output planes or null
   float *yf;                 // optional fp32 output [P][100][COUT]
   float *gap;                // optional [P][COUT]: mean over the 100 pixels (MODE 0)
+  const float *dgap;         // MODE 1, optional [P][CIN]: the input gradient is dgap/100 gated by xh (= forward
+                             // activation hi plane) instead of being read from xh/xl
   int P;
 };
 
@@ -126,13 +166,17 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
 
   // ---- patch -> LDS ------------------------------------------------------------------------------
   {
-    PlaneLoad<CIN, 256> lh, ll;
-    lh.load(a.xh + (long)p * NPIX * CIN, tid);
-    if (SPLIT == 3) ll.load(a.xl + (long)p * NPIX * CIN, tid);
     zero_halo<CIN, 256>(lds, tid);
     if (SPLIT == 3) zero_halo<CIN, 256>(lds + PLANE, tid);
-    lh.store(lds, tid);
-    if (SPLIT == 3) ll.store(lds + PLANE, tid);
+    if (MODE == 1 && a.dgap) {
+      gap_planes_to_lds<CIN, 256, SPLIT>(a.xh + (long)p * NPIX * CIN, a.dgap + (long)p * CIN, lds, lds + PLANE, tid);
+    } else {
+      PlaneLoad<CIN, 256> lh, ll;
+      lh.load(a.xh + (long)p * NPIX * CIN, tid);
+      if (SPLIT == 3) ll.load(a.xl + (long)p * NPIX * CIN, tid);
+      lh.store(lds, tid);
+      if (SPLIT == 3) ll.store(lds + PLANE, tid);
+    }
   }
   __syncthreads();
 
@@ -232,7 +276,7 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
           if (a.yh) {
             const uint16_t h = f2bf(v);
             *reinterpret_cast<uint16_t *>(lds + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = h;
-            if (SPLIT == 3)
+            if (SPLIT == 3 && a.yl)
               *reinterpret_cast<uint16_t *>(lds + PLANE + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = f2bf(v - bf2f(h));
           }
         }
@@ -262,6 +306,7 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
       }
     }
     for (int pl = 0; pl < NPL; ++pl) {
+      if (pl && !a.yl) break;  // the lo plane is optional (nobody reads conv5's)
       uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPIX * COUT;
       const char *src = lds + pl * PLANE;
 #pragma unroll
@@ -292,6 +337,7 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
 struct WgradArgs {
   const uint16_t *dyh, *dyl;  // [P][100][COUT] masked output gradient planes
   const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
+  const float *dgap;          // optional [P][COUT]: dY = dgap/100 gated by dyh (= forward activation hi plane)
   float *dw_part;             // [nslice][COUT][CIN][3][3] fp32 partial sums (every element written)
   float *db_part;             // [nslice][3][COUT] fp32 partial sums
   int P, patches_per_block;
@@ -363,13 +409,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
       // lengthens the HBM queues (measured: all-planes-first was 1.4x slower here)
       xh_.load(a.xh + (long)p * NPIX * CIN, tid);
       xh_.store(xs, tid);
-      yh_.load(a.dyh + (long)p * NPIX * COUT, tid);
-      yh_.store(ys, tid);
+      if (a.dgap) {
+        gap_planes_to_lds<COUT, 512, SPLIT>(a.dyh + (long)p * NPIX * COUT, a.dgap + (long)p * COUT, ys, ys + YPL, tid);
+      } else {
+        yh_.load(a.dyh + (long)p * NPIX * COUT, tid);
+        yh_.store(ys, tid);
+      }
       if (SPLIT == 3) {
         xl_.load(a.xl + (long)p * NPIX * CIN, tid);
         xl_.store(xs + XPL, tid);
-        yl_.load(a.dyl + (long)p * NPIX * COUT, tid);
-        yl_.store(ys + YPL, tid);
+        if (!a.dgap) {
+          yl_.load(a.dyl + (long)p * NPIX * COUT, tid);
+          yl_.store(ys + YPL, tid);
+        }
       }
     }
     __syncthreads();
@@ -596,12 +648,13 @@ int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint1
 
 int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
                     const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi,
-                    uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, crw_stream_t stream) {
+                    uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, const float *dgap, crw_stream_t stream) {
   clear_stale_error();
   if (!x_hi || !w_hi || P < 1 || (mode != 0 && mode != 1) || (split != 1 && split != 3)) return CRW_EINVAL;
-  if (split == 3 && (!x_lo || !w_lo || (y_hi && !y_lo))) return CRW_EINVAL;
+  if (split == 3 && (!w_lo || (!x_lo && !dgap))) return CRW_EINVAL;
+  if (dgap && mode != 1) return CRW_EINVAL;
   if (!y_hi && !y_f32 && !gap) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, P};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P};
   hipStream_t s = (hipStream_t)stream;
 #define CRW_CONV_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
@@ -630,17 +683,17 @@ size_t crw_enc_wgrad_ws_bytes(int P, int cin, int cout, int split) {
 }
 
 int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
-                          const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, void *ws, size_t ws_bytes,
-                          crw_stream_t stream) {
+                          const uint16_t *x_hi, const uint16_t *x_lo, const float *dgap, float *dw, float *db, void *ws,
+                          size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
   if (!dy_hi || !x_hi || !dw || !db || !ws || P < 1 || (split != 1 && split != 3)) return CRW_EINVAL;
-  if (split == 3 && (!dy_lo || !x_lo)) return CRW_EINVAL;
+  if (split == 3 && ((!dy_lo && !dgap) || !x_lo)) return CRW_EINVAL;
   if (ws_bytes < crw_enc_wgrad_ws_bytes(P, cin, cout, split)) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int nslice = wgrad_slices(P, cin, cout, split);
   const int ppb = (P + nslice - 1) / nslice;
   float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
-  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dw_part, db_part, P, ppb};
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb};
   int st = CRW_EINVAL;
 #define CRW_WG_CASE(CI, CO)                                                                  \
   if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);

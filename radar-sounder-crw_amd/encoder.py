@@ -28,7 +28,8 @@ class _HipConv345(torch.autograd.Function):
         x3h, x3l = crw_hip.enc_pack_input(x, split)
         y3h, y3l, _, _ = crw_hip.enc_conv3x3(0, split, x3h, x3l, packed[0][0], packed[0][1], 64, bias=b3)
         y4h, y4l, _, _ = crw_hip.enc_conv3x3(0, split, y3h, y3l, packed[1][0], packed[1][1], 128, bias=b4)
-        y5h, _, _, gap = crw_hip.enc_conv3x3(0, split, y4h, y4l, packed[2][0], packed[2][1], 128, bias=b5, gap=True)
+        y5h, _, _, gap = crw_hip.enc_conv3x3(0, split, y4h, y4l, packed[2][0], packed[2][1], 128, bias=b5, gap=True,
+                                             lo_plane=False)  # only the sign of y5 is needed later
         ctx.split = split
         ctx.planes = (x3h, x3l, y3h, y3l, y4h, y4l, y5h)
         ctx.bwd_w = [(pk[2], pk[3]) for pk in packed]
@@ -39,9 +40,10 @@ class _HipConv345(torch.autograd.Function):
         import crw_hip
         s = ctx.split
         x3h, x3l, y3h, y3l, y4h, y4l, y5h = ctx.planes
-        d5h, d5l = crw_hip.enc_gap_bwd(dgap, y5h, s)                        # dY5 (ReLU5 + GAP backward)
-        dw5, db5 = crw_hip.enc_wgrad(s, d5h, d5l, y4h, y4l)
-        d4h, d4l, _, _ = crw_hip.enc_conv3x3(1, s, d5h, d5l, *ctx.bwd_w[2], 128, mask=y4h)   # dY4 (masked by ReLU4)
+        # dY5 = dgap/100 gated by y5 > 0 (ReLU5 + GAP backward) is built inside the two kernels' loaders
+        dgap = dgap.contiguous().float()
+        dw5, db5 = crw_hip.enc_wgrad(s, y5h, None, y4h, y4l, dgap=dgap)
+        d4h, d4l, _, _ = crw_hip.enc_conv3x3(1, s, y5h, None, *ctx.bwd_w[2], 128, mask=y4h, dgap=dgap)  # dY4
         dw4, db4 = crw_hip.enc_wgrad(s, d4h, d4l, y3h, y3l)
         d3h, d3l, _, _ = crw_hip.enc_conv3x3(1, s, d4h, d4l, *ctx.bwd_w[1], 64, mask=y3h)    # dY3
         dw3, db3 = crw_hip.enc_wgrad(s, d3h, d3l, x3h, x3l)

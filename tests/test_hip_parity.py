@@ -225,6 +225,15 @@ def test_encoder_conv_kernels_match_torch(hip, cin, cout, split):
     torch.testing.assert_close(dxf.cpu().double(), dx_ref.permute(0, 2, 3, 1).reshape(P, 100, cin), **tol)
     dmh, dml, _, _ = hip.enc_conv3x3(1, split, dyh, dyl, bh, bl, cin, mask=maskp)
     torch.testing.assert_close(_planes_value(dmh, dml).cpu().double(), _to_planes_ref(dx_ref * (x > 0)), **tol)
+    if cout == 128:  # fused ReLU + GAP backward: dY = dgap/100 gated by the forward activation plane
+        dgap = torch.randn(P, cout, generator=g).cuda()
+        gh, gl = hip.enc_gap_bwd(dgap, yh, split)
+        a1 = hip.enc_conv3x3(1, split, gh, gl, bh, bl, cin, mask=maskp)
+        a2 = hip.enc_conv3x3(1, split, yh, None, bh, bl, cin, mask=maskp, dgap=dgap)
+        assert torch.equal(a1[0], a2[0]) and (split == 1 or torch.equal(a1[1], a2[1]))
+        w1 = hip.enc_wgrad(split, gh, gl, xh, xl)
+        w2 = hip.enc_wgrad(split, yh, None, xh, xl, dgap=dgap)
+        assert torch.equal(w1[0], w2[0]) and torch.equal(w1[1], w2[1])
     # weight / bias gradient
     dw, db = hip.enc_wgrad(split, dyh, dyl, xh, xl)
     dw_ref = torch.nn.grad.conv2d_weight(xq, w.shape, dyq, padding=1)
