@@ -22,9 +22,10 @@
 //
 // conv3x3_wgrad_kernel: dW[co,ci,tap] = sum_{p,pix} dY[p,pix,co] * X[p,pix+tap,ci]: both operands
 // are pixel-major in memory, i.e. strided along the reduction dimension, so fragments come from
-// LDS through the hardware-transposing ds_read_b64_tr_b16.  One workgroup owns one tap row (3
-// taps), walks a slice of the patches accumulating in registers, then adds its partial sums to
-// the fp32 gradient with atomics.
+// LDS through the hardware-transposing ds_read_b64_tr_b16.  One workgroup owns all 9 taps x all
+// output channels x a group of 64 input channels, walks a slice of the patches accumulating in
+// registers, and writes its partial sums to a workspace; a second kernel adds the slices in a
+// fixed order (bitwise reproducible, no float atomics).
 #include "crw_common.h"
 #include <type_traits>
 
@@ -339,7 +340,7 @@ struct WgradArgs {
   const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
   const float *dgap;          // optional [P][COUT]: dY = dgap/100 gated by dyh (= forward activation hi plane)
   float *dw_part;             // [nslice][COUT][CIN][3][3] fp32 partial sums (every element written)
-  float *db_part;             // [nslice][3][COUT] fp32 partial sums
+  float *db_part;             // [nslice][CIN/NCI][COUT] fp32 partial sums
   int P, patches_per_block;
 };
 
@@ -361,32 +362,34 @@ __device__ inline bf8 tr_frag(uint32_t a_lo, uint32_t a_hi) {
   return __builtin_bit_cast(bf8, v);
 }
 
-template <int SPLIT, int CIN, int COUT>
+// NCI = input channels per workgroup (blockIdx.x selects the group): the workgroup holds all 9 taps
+// x all COUT x NCI input channels in its accumulators, so a patch is fetched by CIN/NCI workgroups
+// (2 for conv5) instead of once per tap row, and only the NCI-channel slice of the X planes is loaded.
+template <int SPLIT, int CIN, int COUT, int NCI>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
-  constexpr int XPL = plane_bytes<CIN>(), YPL = plane_bytes<COUT>();  // bytes per LDS plane
-  constexpr int MTW = COUT / 128 > 0 ? COUT / 128 : 1;        // 16-wide co tiles per wave (8 waves)
-  constexpr int COW = COUT / 8;                               // co per wave (16 or 8 -> see below)
-  static_assert(COUT % 128 == 0 || COUT == 64, "COUT");
-  constexpr int NT = CIN / 16;                                // ci tiles
+  constexpr int XPL = plane_bytes<NCI>(), YPL = plane_bytes<COUT>();  // bytes per LDS plane
+  static_assert(COUT == 128 || COUT == 64, "COUT");
+  constexpr int NT = NCI / 16;  // ci tiles of this group
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *xs = lds, *ys = lds + NPL * XPL;
 
-  const int dy = blockIdx.x;  // tap row
+  const int grp = blockIdx.x, ci_base = grp * NCI;
+  constexpr int NGRP = CIN / NCI;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  // COUT = 64: only 4 co tiles exist; waves 4..7 take the same tiles as 0..3 but the other half of the ci tiles
+  // COUT = 128: wave w owns output channels [16 w, 16 w + 16) and all NT ci tiles.
+  // COUT = 64 : only 4 co tiles exist; waves 4..7 repeat them on the other half of the ci tiles.
   constexpr bool SPLIT_N = (COUT == 64);
-  const int co0 = SPLIT_N ? (wave & 3) * 16 : wave * COW;
+  const int co0 = SPLIT_N ? (wave & 3) * 16 : wave * 16;
   constexpr int NTW = SPLIT_N ? NT / 2 : NT;  // ci tiles per wave
+  static_assert(NTW >= 1, "tiles");
   const int nt0 = SPLIT_N ? (wave >> 2) * NTW : 0;
 
-  f32x4 acc[3][MTW][NTW];
+  f32x4 acc[9][NTW];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbsum = 0.f;
 
   const int p_begin = blockIdx.y * a.patches_per_block;
@@ -394,45 +397,53 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
 
   // the halo of the LDS images is zeroed once; patch loads only ever touch the interior
-  zero_halo<CIN, 512>(xs, tid);
+  zero_halo<NCI, 512>(xs, tid);
   zero_halo<COUT, 512>(ys, tid);
   if (SPLIT == 3) {
-    zero_halo<CIN, 512>(xs + XPL, tid);
+    zero_halo<NCI, 512>(xs + XPL, tid);
     zero_halo<COUT, 512>(ys + YPL, tid);
   }
+  constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + 511) / 512;
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();  // previous patch fully consumed
     {
-      PlaneLoad<CIN, 512> xh_, xl_;
-      PlaneLoad<COUT, 512> yh_, yl_;
-      // plane by plane: with every CU in its load phase at once, more bytes in flight per CU only
-      // lengthens the HBM queues (measured: all-planes-first was 1.4x slower here)
-      xh_.load(a.xh + (long)p * NPIX * CIN, tid);
-      xh_.store(xs, tid);
+      // X: the NCI-channel slice [ci_base, ci_base + NCI) of every interior pixel (hi, then lo)
+      uint4 xv[XIT];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const uint16_t *src = (pl ? a.xl : a.xh) + (long)p * NPIX * CIN + ci_base;
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+          const int c = tid + i * 512;
+          if (XTOT % 512 == 0 || c < XTOT) xv[i] = *reinterpret_cast<const uint4 *>(src + (long)(c / XCH) * CIN + 8 * (c % XCH));
+        }
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+          const int c = tid + i * 512;
+          if (XTOT % 512 == 0 || c < XTOT)
+            *reinterpret_cast<uint4 *>(xs + pl * XPL + px_off<NCI>(interior_pp(c / XCH), c % XCH)) = xv[i];
+        }
+      }
       if (a.dgap) {
         gap_planes_to_lds<COUT, 512, SPLIT>(a.dyh + (long)p * NPIX * COUT, a.dgap + (long)p * COUT, ys, ys + YPL, tid);
       } else {
+        PlaneLoad<COUT, 512> yh_, yl_;
         yh_.load(a.dyh + (long)p * NPIX * COUT, tid);
         yh_.store(ys, tid);
-      }
-      if (SPLIT == 3) {
-        xl_.load(a.xl + (long)p * NPIX * CIN, tid);
-        xl_.store(xs + XPL, tid);
-        if (!a.dgap) {
+        if (SPLIT == 3) {
           yl_.load(a.dyl + (long)p * NPIX * COUT, tid);
           yl_.store(ys + YPL, tid);
         }
       }
     }
     __syncthreads();
-    // bias gradient: every thread takes channel tid % COUT and every (512/COUT * 3)-th interior pixel
-    // (the three tap-row workgroups of a patch slice share the pixels, so the extra work is balanced)
+    // bias gradient: thread -> channel tid % COUT, pixels part, part + PARTS*NGRP, ... of this group's share
     {
       constexpr int PARTS = 512 / COUT;
       const int c = tid % COUT, part = tid / COUT;
       float s = 0.f;
-      for (int i = part * 3 + dy; i < NPIX; i += PARTS * 3) {
-        const int o = px_off<COUT>((i / IMG_W + 1) * PAD_W + (i % IMG_W + 1), c >> 3) + 2 * (c & 7);
+      for (int i = part * NGRP + grp; i < NPIX; i += PARTS * NGRP) {
+        const int o = px_off<COUT>(interior_pp(i), c >> 3) + 2 * (c & 7);
         s += bf2f(*reinterpret_cast<const uint16_t *>(ys + o));
         if (SPLIT == 3) s += bf2f(*reinterpret_cast<const uint16_t *>(ys + YPL + o));
       }
@@ -448,21 +459,20 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll 1
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
-      const int py_lo = i_lo < NPIX ? (i_lo / IMG_W + 1) * PAD_W + (i_lo % IMG_W + 1) : 0;
-      const int py_hi = i_hi < NPIX ? (i_hi / IMG_W + 1) * PAD_W + (i_hi % IMG_W + 1) : 0;
-      const int px_lo = (i_lo < NPIX ? py_lo : PAD_W + 1) + (dy - 1) * PAD_W - 1;  // tap dx = 0
-      const int px_hi = (i_hi < NPIX ? py_hi : PAD_W + 1) + (dy - 1) * PAD_W - 1;
+      const int py_lo = i_lo < NPIX ? interior_pp(i_lo) : 0;
+      const int py_hi = i_hi < NPIX ? interior_pp(i_hi) : 0;
+      const int px_lo = (i_lo < NPIX ? py_lo : PAD_W + 1) - PAD_W - 1;  // tap (dy, dx) = (0, 0)
+      const int px_hi = (i_hi < NPIX ? py_hi : PAD_W + 1) - PAD_W - 1;
       const uint32_t ya_lo = ys_a + py_lo * row_stride<COUT>() + lane_col + 2 * co0;
       const uint32_t ya_hi = ys_a + py_hi * row_stride<COUT>() + lane_col + 2 * co0;
-      const uint32_t xa_lo = xs_a + px_lo * row_stride<CIN>() + lane_col + 32 * nt0;
-      const uint32_t xa_hi = xs_a + px_hi * row_stride<CIN>() + lane_col + 32 * nt0;
-      bf8 ah[MTW], al[MTW];
-      ah[0] = tr_frag<0>(ya_lo, ya_hi);
-      if (SPLIT == 3) al[0] = tr_frag<YPL>(ya_lo, ya_hi);
-      static_assert(MTW == 1, "one co tile per wave");
-      auto taps = [&](auto DXC) {
-        constexpr int dx = decltype(DXC)::value;
-        constexpr int XO = dx * row_stride<CIN>();  // tap shift = dx pixels to the right
+      const uint32_t xa_lo = xs_a + px_lo * row_stride<NCI>() + lane_col + 32 * nt0;
+      const uint32_t xa_hi = xs_a + px_hi * row_stride<NCI>() + lane_col + 32 * nt0;
+      const bf8 ah = tr_frag<0>(ya_lo, ya_hi);
+      bf8 al;
+      if (SPLIT == 3) al = tr_frag<YPL>(ya_lo, ya_hi);
+      auto tap_fn = [&](auto TC) {
+        constexpr int tap = decltype(TC)::value;
+        constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * row_stride<NCI>();  // tap shift in LDS bytes
         bf8 bh[NTW], bl[NTW];
         auto rd = [&](auto JC) {
           constexpr int j = decltype(JC)::value;
@@ -473,40 +483,38 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
         };
         rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{});
         rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
-        rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{});
-        rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           if (SPLIT == 3) {
-            acc[dx][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh[j], acc[dx][0][j], 0, 0, 0);
-            acc[dx][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl[j], acc[dx][0][j], 0, 0, 0);
+            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[tap][j], 0, 0, 0);
+            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[tap][j], 0, 0, 0);
           }
-          acc[dx][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh[j], acc[dx][0][j], 0, 0, 0);
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[tap][j], 0, 0, 0);
         }
       };
-      taps(std::integral_constant<int, 0>{});
-      taps(std::integral_constant<int, 1>{});
-      taps(std::integral_constant<int, 2>{});
+      tap_fn(std::integral_constant<int, 0>{}); tap_fn(std::integral_constant<int, 1>{});
+      tap_fn(std::integral_constant<int, 2>{}); tap_fn(std::integral_constant<int, 3>{});
+      tap_fn(std::integral_constant<int, 4>{}); tap_fn(std::integral_constant<int, 5>{});
+      tap_fn(std::integral_constant<int, 6>{}); tap_fn(std::integral_constant<int, 7>{});
+      tap_fn(std::integral_constant<int, 8>{});
     }
   }
 
   // partial sums of this patch slice -> workspace (plain stores; a second kernel adds the slices
   // in a fixed order, so gradients are bitwise reproducible and no float atomics are needed).
-  // acc[dx][i][j][r] = dW[co0 + 16 i + 4 g + r][ci 16 (nt0+j) + lane&15][dy][dx]
+  // acc[tap][j][r] = dW[co0 + 4 g + r][ci_base + 16 (nt0 + j) + lane&15][tap]
   float *dwp = a.dw_part + (long)blockIdx.y * COUT * CIN * 9;
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx)
+  for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + 16 * i + 4 * g + r, ci = 16 * (nt0 + j) + (lane & 15);
-          dwp[(((long)co * CIN + ci) * 3 + dy) * 3 + dx] = acc[dx][i][j][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + 4 * g + r, ci = ci_base + 16 * (nt0 + j) + (lane & 15);
+        dwp[((long)co * CIN + ci) * 9 + tap] = acc[tap][j][r];
+      }
   // bias partials: reduce the 512/COUT pixel parts of each channel through LDS
   __syncthreads();
   float *red = reinterpret_cast<float *>(lds);
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
   if (tid < COUT) {
     float s = 0.f;
     for (int part = 0; part < 512 / COUT; ++part) s += red[part * COUT + tid];
-    a.db_part[((long)blockIdx.y * 3 + dy) * COUT + tid] = s;
+    a.db_part[((long)blockIdx.y * NGRP + grp) * COUT + tid] = s;
   }
 }
 
@@ -592,19 +600,23 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
   return check_launch();
 }
 
+// input channels per workgroup: 64 keeps 9 taps x 4 ci tiles = 144 accumulator registers per lane
+constexpr int wgrad_nci(int cin) { return cin > 64 ? 64 : cin; }
+
 template <int SPLIT, int CIN, int COUT>
 int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (plane_bytes<CIN>() + plane_bytes<COUT>());
+  constexpr int NCI = wgrad_nci(CIN);
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (plane_bytes<NCI>() + plane_bytes<COUT>());
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT>,
+    if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT>), dim3(3, nblk), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>), dim3(CIN / NCI, nblk), dim3(512), lds, s, a);
   return check_launch();
 }
 
@@ -670,16 +682,19 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
   return CRW_EINVAL;
 }
 
+static int wgrad_groups(int cin) { return cin / wgrad_nci(cin); }
+
 static int wgrad_slices(int P, int cin, int cout, int split) {
-  const size_t lds = (size_t)(split == 3 ? 2 : 1) * NPAD * ((size_t)(cin + cout) * 2 + 32);
+  const size_t lds = (size_t)(split == 3 ? 2 : 1) * NPAD * ((size_t)(wgrad_nci(cin) + cout) * 2 + 32);
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;  // workgroups of 512 threads per CU
-  int n = 256 * per_cu / 3;                     // three tap-row workgroups per slice
+  int n = 256 * per_cu / wgrad_groups(cin);     // one workgroup per (slice, ci group)
   return n > P ? P : n;
 }
 
 size_t crw_enc_wgrad_ws_bytes(int P, int cin, int cout, int split) {
   if (P < 1 || cin < 1 || cout < 1) return 0;
-  return (size_t)wgrad_slices(P, cin, cout, split) * ((size_t)cout * cin * 9 + 3 * (size_t)cout) * sizeof(float);
+  return (size_t)wgrad_slices(P, cin, cout, split) *
+         ((size_t)cout * cin * 9 + (size_t)wgrad_groups(cin) * cout) * sizeof(float);
 }
 
 int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
@@ -704,7 +719,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
   hipLaunchKernelGGL(slice_sum_kernel, dim3(ew_grid(nw)), dim3(256), 0, s, dw_part, nslice, nw, dw);
-  hipLaunchKernelGGL(slice_sum_kernel, dim3(1), dim3(256), 0, s, db_part, nslice * 3, (long)cout, db);
+  hipLaunchKernelGGL(slice_sum_kernel, dim3(1), dim3(256), 0, s, db_part, nslice * wgrad_groups(cin), (long)cout, db);
   return check_launch();
 }
 
