@@ -145,6 +145,23 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
                           const uint16_t *x_hi, const uint16_t *x_lo, const float *dgap, float *dw, float *db,
                           void *ws, size_t ws_bytes, crw_stream_t stream);
 
+/* encoder front end: conv1 5x5 -> ReLU -> maxpool 2x2/1 -> conv2 5x5 -> ReLU -> maxpool 2x2/1, fused
+ * (src/encoder.py:13-24,46-47; 16x16 patches, cin = 1 or 2 with pos_embed) -------------------------- */
+/* conv2 weight [32][8][5][5] fp32 -> forward planes [7][32][32] and backward planes [25][8][32] */
+int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi, uint16_t *bwd_lo,
+                       crw_stream_t stream);
+/* x [P][cin][16][16] fp32 -> planes [P][100][32] (input of crw_enc_conv3x3 cin = 32) */
+int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
+                      const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi,
+                      uint16_t *y_lo, crw_stream_t stream);
+/* backward (recomputes the forward per patch): dy [P][100][32] fp32 -> dw1 [8][cin][5][5], db1 [8],
+ * dw2 [32][8][5][5], db2 [32]; partial sums per patch slice in `ws`, added in a fixed order. */
+size_t crw_enc_front_ws_bytes(int P, int cin);
+int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
+                      const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const uint16_t *w2b_hi,
+                      const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2,
+                      void *ws, size_t ws_bytes, crw_stream_t stream);
+
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous
  * call, e.g. when timing the GEMM alone).  split = 1: plain bf16 operands; split = 3: hi/lo operand

@@ -42,6 +42,11 @@ SIGNATURES = {
     "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p]),
     "crw_enc_wgrad_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
+    "crw_enc_front_pack": (_c_int, [_p, _p, _p, _p, _p, _p]),
+    "crw_enc_front_fwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_front_ws_bytes": (_c_sz, [_c_int, _c_int]),
+    "crw_enc_front_bwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                   _c_sz, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -261,3 +266,42 @@ def enc_wgrad(split, dyh, dyl, xh, xl, dgap=None):
                                        _dev(dw, "dw"), _dev(db, "db"), ctypes.c_void_p(ws.data_ptr()),
                                        nbytes, _stream()), "crw_enc_conv3x3_wgrad")
     return dw, db
+
+
+def enc_front_pack(w2, split):
+    """conv2 weight [32,8,5,5] -> (fwd_hi, fwd_lo, bwd_hi, bwd_lo) bf16 planes."""
+    fh = torch.empty(7, 32, 32, dtype=_BF, device=w2.device)
+    bh = torch.empty(25, 8, 32, dtype=_BF, device=w2.device)
+    fl, bl = (torch.empty_like(fh), torch.empty_like(bh)) if split == 3 else (None, None)
+    _check(lib().crw_enc_front_pack(_dev(w2.contiguous(), "w2"), _bf(fh, "fh"), _bf(fl, "fl"), _bf(bh, "bh"),
+                                    _bf(bl, "bl"), _stream()), "crw_enc_front_pack")
+    return fh, fl, bh, bl
+
+
+def enc_front_fwd(split, x, w1, b1, w2f, b2):
+    """x [P,cin,16,16] -> planes [P,100,32] (conv1-ReLU-pool-conv2-ReLU-pool)."""
+    P, cin = x.shape[:2]
+    yh = torch.empty(P, 100, 32, dtype=_BF, device=x.device)
+    yl = torch.empty_like(yh) if split == 3 else None
+    _check(lib().crw_enc_front_fwd(split, _dev(x, "x"), P, cin, _dev(w1.contiguous(), "w1"), _dev(b1, "b1"),
+                                   _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"), _bf(yh, "yh"), _bf(yl, "yl"),
+                                   _stream()), "crw_enc_front_fwd")
+    return yh, yl
+
+
+def enc_front_bwd(split, x, w1, b1, w2f, b2, w2b, dy):
+    """-> (dw1, db1, dw2, db2)"""
+    P, cin = x.shape[:2]
+    dev = x.device
+    dw1 = torch.empty(8, cin, 5, 5, device=dev)
+    db1 = torch.empty(8, device=dev)
+    dw2 = torch.empty(32, 8, 5, 5, device=dev)
+    db2 = torch.empty(32, device=dev)
+    nbytes = lib().crw_enc_front_ws_bytes(P, cin)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _check(lib().crw_enc_front_bwd(split, _dev(x, "x"), P, cin, _dev(w1.contiguous(), "w1"), _dev(b1, "b1"),
+                                   _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"), _bf(w2b[0], "w2bh"),
+                                   _bf(w2b[1], "w2bl"), _dev(dy.contiguous(), "dy"), _dev(dw1, "dw1"), _dev(db1, "db1"),
+                                   _dev(dw2, "dw2"), _dev(db2, "db2"), ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()),
+           "crw_enc_front_bwd")
+    return dw1, db1, dw2, db2

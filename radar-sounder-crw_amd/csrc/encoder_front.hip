@@ -1,0 +1,605 @@
+// Fused front end of the CNN encoder (src/encoder.py:13-24,46-47):
+//     x [cin,16,16] -> conv1 5x5 pad 1 (cin->8) -> ReLU -> maxpool 2x2/1 -> conv2 5x5 pad 1 (8->32)
+//       -> ReLU -> maxpool 2x2/1 -> [100][32] channels-last bf16 planes (hi[,lo]) for conv3.
+// One persistent workgroup (256 threads) streams patches; everything between the 1 KB input patch
+// and the 6.4 KB output planes stays in LDS.
+//   conv1 (25*cin MACs per output, 3 % of this stage): fp32 VALU, exact.
+//   conv2 (200 MACs per output): implicit GEMM on v_mfma_f32_16x16x32_bf16 with k = (tap, ci): one
+//     32-deep k-step = 4 taps x 8 input channels, so an A fragment is ONE 16-byte channels-last read
+//     of the pixel shifted by the lane group's tap.  SPLIT = 3 uses hi/lo operand pairs (fp32-grade).
+// The backward kernel recomputes this forward per patch (cheaper than storing c1/a1/c2 and the
+// pooling indices: 30 KB per patch) and then runs, per patch,
+//     pool2/ReLU2 backward -> conv2 weight gradient (MFMA, transposed LDS reads) and bias gradient
+//     -> conv2 backward-data (MFMA) -> pool1/ReLU1 backward -> conv1 weight/bias gradient (VALU),
+// accumulating the weight gradients in registers over its slice of patches; slices are added in a
+// fixed order by slice_sum (deterministic).
+#include "crw_common.h"
+#include <type_traits>
+
+namespace crw {
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char *lds_cp;
+
+__device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+// geometry
+constexpr int XW = 16, XPW = 18;           // input patch, padded by 1
+constexpr int C1W = 14, C1N = C1W * C1W;   // conv1 output 14x14
+constexpr int A1W = 13, A1PW = 15;         // pool1 output 13x13, padded by 1 -> 15x15
+constexpr int C2W = 11, C2N = C2W * C2W;   // conv2 output 11x11 (121)
+constexpr int OW = 10, ON = 100;           // pool2 output
+constexpr int D2PW = 19;                   // conv2-output gradient padded by 4 (for backward-data)
+constexpr int KS2 = 7;                     // conv2 k-steps (28 taps, 25 real)
+
+struct FrontArgs {
+  const float *x;            // [P][cin][16][16]
+  const float *w1, *b1;      // [8][cin][5][5], [8]
+  const uint16_t *w2h, *w2l; // packed conv2 weights [7][32 co][32 k], k = 8*(tap%4) + ci, tap = 4*s + ..
+  const float *b2;           // [32]
+  uint16_t *yh, *yl;         // out planes [P][100][32]
+  int P, cin;
+};
+
+// ---- shared forward pieces ----------------------------------------------------------------------
+struct FwdLds {
+  float *xs;      // [cin][18][18]
+  float *w1;      // [8][cin][25] + b1[8]
+  float *c1r;     // [196][8]
+  char *a1h, *a1l;  // [225][8] bf16 (16 B per pixel)
+  char *w2h, *w2l;  // [7][32][32] bf16
+  float *c2r;     // [121][32]
+};
+
+__device__ inline void load_patch(const float *__restrict__ x, int cin, float *xs, int tid) {
+  for (int e = tid; e < cin * 256; e += 256) {
+    const int c = e >> 8, r = (e >> 4) & 15, col = e & 15;
+    xs[(c * XPW + r + 1) * XPW + col + 1] = x[e];
+  }
+}
+
+// conv1 + bias + ReLU: thread = output pixel (196 of 256 threads), all 8 channels
+__device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
+  if (tid < C1N) {
+    const int y = tid / C1W, xx = tid % C1W;
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = L.w1[8 * cin * 25 + co];
+    for (int ci = 0; ci < cin; ++ci)
+#pragma unroll
+      for (int t = 0; t < 25; ++t) {
+        const float v = L.xs[(ci * XPW + y + t / 5) * XPW + xx + t % 5];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, L.w1[(co * cin + ci) * 25 + t], acc[co]);
+      }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) L.c1r[tid * 8 + co] = fmaxf(acc[co], 0.f);
+  }
+}
+
+// maxpool 2x2/1 of c1r -> a1 planes (interior of the 15x15 padded image)
+template <int SPLIT>
+__device__ inline void pool1(const FwdLds &L, int tid) {
+  for (int e = tid; e < A1W * A1W * 8; e += 256) {
+    const int c = e & 7, p = e >> 3, y = p / A1W, x = p % A1W;
+    const float *s = L.c1r + (y * C1W + x) * 8 + c;
+    const float v = fmaxf(fmaxf(s[0], s[8]), fmaxf(s[C1W * 8], s[C1W * 8 + 8]));
+    const uint16_t h = f2bf(v);
+    const int o = ((y + 1) * A1PW + x + 1) * 16 + 2 * c;
+    *reinterpret_cast<uint16_t *>(L.a1h + o) = h;
+    if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + o) = f2bf(v - bf2f(h));
+  }
+}
+
+// conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  wave w owns row tiles 2w, 2w+1.
+template <int SPLIT>
+__device__ inline void conv2_relu(const FwdLds &L, const float *__restrict__ b2, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  int base[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int i = 16 * (2 * wave + k) + r16;
+    if (i >= C2N) i = 0;
+    base[k] = (i / C2W) * A1PW + (i % C2W);  // padded a1 pixel of tap (0,0)
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS2; ++s) {
+    int tap = 4 * s + g;
+    if (tap > 24) tap = 24;  // k-steps beyond tap 24 carry zero weights
+    const int toff = (tap / 5) * A1PW + (tap % 5);
+    bf8 bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = ((s * 32 + 16 * j + r16) * 32 + 8 * g) * 2;
+      bh[j] = *reinterpret_cast<const bf8 *>(L.w2h + o);
+      if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf8 *>(L.w2l + o);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bf8 ah = *reinterpret_cast<const bf8 *>(L.a1h + (base[k] + toff) * 16);
+      bf8 al;
+      if (SPLIT == 3) al = *reinterpret_cast<const bf8 *>(L.a1l + (base[k] + toff) * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (SPLIT == 3) {
+          acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[k][j], 0, 0, 0);
+          acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[k][j], 0, 0, 0);
+        }
+        acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[k][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = 16 * j + r16;
+      const float b = b2[co];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * (2 * wave + k) + 4 * g + r;
+        if (i < C2N) L.c2r[i * 32 + co] = fmaxf(acc[k][j][r] + b, 0.f);
+      }
+    }
+}
+
+__device__ inline FwdLds carve_fwd(char *&p, int cin) {
+  FwdLds L;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
+  L.xs = (float *)take(sizeof(float) * cin * XPW * XPW);
+  L.w1 = (float *)take(sizeof(float) * (8 * cin * 25 + 8));
+  L.c1r = (float *)take(sizeof(float) * C1N * 8);
+  L.a1h = take(A1PW * A1PW * 16);
+  L.a1l = take(A1PW * A1PW * 16);
+  L.w2h = take(KS2 * 32 * 32 * 2);
+  L.w2l = take(KS2 * 32 * 32 * 2);
+  L.c2r = (float *)take(sizeof(float) * C2N * 32);
+  return L;
+}
+
+template <int SPLIT>
+__device__ inline void stage_constants(const FwdLds &L, const FrontArgs &a, int tid) {
+  for (int e = tid; e < a.cin * XPW * XPW; e += 256) L.xs[e] = 0.f;  // zero border of the padded patch
+  for (int e = tid; e < 8 * a.cin * 25; e += 256) L.w1[e] = a.w1[e];
+  if (tid < 8) L.w1[8 * a.cin * 25 + tid] = a.b1[tid];
+  for (int e = tid; e < A1PW * A1PW * 4; e += 256) {  // zero halo (and interior) of the a1 planes
+    reinterpret_cast<uint32_t *>(L.a1h)[e] = 0;
+    reinterpret_cast<uint32_t *>(L.a1l)[e] = 0;
+  }
+  for (int e = tid; e < KS2 * 32 * 32 / 8; e += 256) {
+    reinterpret_cast<uint4 *>(L.w2h)[e] = reinterpret_cast<const uint4 *>(a.w2h)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[e] = reinterpret_cast<const uint4 *>(a.w2l)[e];
+  }
+}
+
+template <int SPLIT>
+__global__ __launch_bounds__(256) void front_fwd_kernel(FrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char *p = lds;
+  const FwdLds L = carve_fwd(p, a.cin);
+  const int tid = threadIdx.x;
+  stage_constants<SPLIT>(L, a, tid);
+  __syncthreads();
+  for (int pt = blockIdx.x; pt < a.P; pt += gridDim.x) {
+    load_patch(a.x + (long)pt * a.cin * 256, a.cin, L.xs, tid);
+    __syncthreads();
+    conv1_relu(L, a.cin, tid);
+    __syncthreads();
+    pool1<SPLIT>(L, tid);
+    __syncthreads();
+    conv2_relu<SPLIT>(L, a.b2, tid);
+    __syncthreads();
+    // maxpool 2x2/1 -> output planes [100][32]
+    for (int e = tid; e < ON * 32; e += 256) {
+      const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
+      const float *s = L.c2r + (y * C2W + x) * 32 + c;
+      const float v = fmaxf(fmaxf(s[0], s[32]), fmaxf(s[C2W * 32], s[C2W * 32 + 32]));
+      const uint16_t h = f2bf(v);
+      a.yh[(long)pt * ON * 32 + e] = h;
+      if (SPLIT == 3) a.yl[(long)pt * ON * 32 + e] = f2bf(v - bf2f(h));
+    }
+    // the next iteration's first barrier orders these c2r reads before conv2_relu overwrites it
+  }
+}
+
+// fp32 conv2 weight [32][8][5][5] -> forward planes [7][32 co][32 k] (k = 8*(tap-4s) + ci, zero beyond tap 24)
+//                                 -> backward planes [25 tap][8 ci][32 co]
+__global__ __launch_bounds__(256) void pack_w2_kernel(const float *__restrict__ w, uint16_t *fh, uint16_t *fl,
+                                                      uint16_t *bh, uint16_t *bl) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < KS2 * 32 * 32; e += gridDim.x * 256) {
+    const int k = e & 31, co = (e >> 5) & 31, s = e >> 10;
+    const int tap = 4 * s + (k >> 3), ci = k & 7;
+    const float v = tap < 25 ? w[(co * 8 + ci) * 25 + tap] : 0.f;
+    const uint16_t h = f2bf(v);
+    fh[e] = h;
+    if (fl) fl[e] = f2bf(v - bf2f(h));
+  }
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < 25 * 8 * 32; e += gridDim.x * 256) {
+    const int co = e & 31, ci = (e >> 5) & 7, tap = e >> 8;
+    const float v = w[(co * 8 + ci) * 25 + tap];
+    const uint16_t h = f2bf(v);
+    bh[e] = h;
+    if (bl) bl[e] = f2bf(v - bf2f(h));
+  }
+}
+
+// ---- backward -------------------------------------------------------------------------------------
+struct FrontBwdArgs {
+  FrontArgs f;               // forward inputs (yh/yl unused)
+  const uint16_t *w2bh, *w2bl;  // conv2 backward planes [25][8][32]
+  const float *dy;           // [P][100][32] fp32 gradient of the pool2 output
+  float *part;               // [nslice][PART] partial sums: dW2 [32][8][25], db2 [32], dW1 [8][cin][25], db1 [8]
+  int patches_per_block;
+};
+
+__device__ inline s4v tr_read0(uint32_t lds_addr) {
+  s4v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+__device__ inline bf8 tr_pair(uint32_t a_lo, uint32_t a_hi) {
+  const s4v lo = tr_read0(a_lo), hi = tr_read0(a_hi);
+  const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8, v);
+}
+
+// index (0..3) of the first maximum of a 2x2 window in row-major order (torch's max_pool2d tie rule)
+__device__ inline int argmax4(float a, float b, float c, float d) {
+  int k = 0;
+  float m = a;
+  if (b > m) { m = b; k = 1; }
+  if (c > m) { m = c; k = 2; }
+  if (d > m) { m = d; k = 3; }
+  return k;
+}
+
+template <int SPLIT>
+__global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char *p = lds;
+  const int cin = a.f.cin;
+  const FwdLds L = carve_fwd(p, cin);
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
+  char *wbh = take(25 * 8 * 32 * 2), *wbl = take(25 * 8 * 32 * 2);
+  char *d2h = take(D2PW * D2PW * 64), *d2l = take(D2PW * D2PW * 64);  // dC2 (masked), padded by 4, [pix][32] bf16
+  float *dyb = (float *)take(sizeof(float) * ON * 32);                // dy of this patch; later dA1 [169][8] + dC1 [196][8]
+  float *dA1 = dyb, *dC1 = dyb + A1W * A1W * 8;
+  static_assert(A1W * A1W * 8 + C1N * 8 <= ON * 32, "alias");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  stage_constants<SPLIT>(L, a.f, tid);
+  for (int e = tid; e < 25 * 8 * 32 / 8; e += 256) {
+    reinterpret_cast<uint4 *>(wbh)[e] = reinterpret_cast<const uint4 *>(a.w2bh)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(wbl)[e] = reinterpret_cast<const uint4 *>(a.w2bl)[e];
+  }
+  for (int e = tid; e < D2PW * D2PW * 16; e += 256) {  // zero the padded gradient planes once (halo stays zero)
+    reinterpret_cast<uint32_t *>(d2h)[e] = 0;
+    reinterpret_cast<uint32_t *>(d2l)[e] = 0;
+  }
+  __syncthreads();
+
+  // conv2 weight-gradient tiles: M = 32 co (2 tiles), N = 13 tiles of (2 taps x 8 ci); wave w owns N tiles w, w+4, ...
+  f32x4 wacc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2 = 0.f, dw1[2] = {0.f, 0.f}, db1 = 0.f;
+
+  const uint32_t d2h_a = (uint32_t)(uintptr_t)(lds_cp)d2h, d2l_a = (uint32_t)(uintptr_t)(lds_cp)d2l;
+  const uint32_t a1h_a = (uint32_t)(uintptr_t)(lds_cp)L.a1h, a1l_a = (uint32_t)(uintptr_t)(lds_cp)L.a1l;
+
+  const int p_begin = blockIdx.x * a.patches_per_block;
+  const int p_end = min(a.f.P, p_begin + a.patches_per_block);
+  for (int pt = p_begin; pt < p_end; ++pt) {
+    // ---- recompute the forward of this patch ---------------------------------------------------
+    load_patch(a.f.x + (long)pt * cin * 256, cin, L.xs, tid);
+    for (int e = tid; e < ON * 32; e += 256) dyb[e] = a.dy[(long)pt * ON * 32 + e];
+    __syncthreads();
+    conv1_relu(L, cin, tid);
+    __syncthreads();
+    pool1<SPLIT>(L, tid);
+    __syncthreads();
+    conv2_relu<SPLIT>(L, a.f.b2, tid);
+    __syncthreads();
+
+    // ---- pool2 + ReLU2 backward: dC2[pix][co] (masked) -> padded bf16 planes, bias gradient ------
+    for (int e = tid; e < C2N * 32; e += 256) {
+      const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
+      float gsum = 0.f;
+      const float mine = L.c2r[e];
+      if (mine > 0.f) {
+        // windows (wy, wx) with wy in {y-1, y}, wx in {x-1, x} contain this pixel at position (y-wy, x-wx)
+#pragma unroll
+        for (int dyw = 0; dyw < 2; ++dyw)
+#pragma unroll
+          for (int dxw = 0; dxw < 2; ++dxw) {
+            const int wy = y - dyw, wx = x - dxw;
+            if (wy >= 0 && wy < OW && wx >= 0 && wx < OW) {
+              const float *s = L.c2r + (wy * C2W + wx) * 32 + co;
+              if (argmax4(s[0], s[32], s[C2W * 32], s[C2W * 32 + 32]) == dyw * 2 + dxw) gsum += dyb[(wy * OW + wx) * 32 + co];
+            }
+          }
+      }
+      db2 += gsum;  // thread t always meets channel t & 31
+      const uint16_t h = f2bf(gsum);
+      const int o = ((y + 4) * D2PW + x + 4) * 64 + 2 * co;
+      *reinterpret_cast<uint16_t *>(d2h + o) = h;
+      if (SPLIT == 3) *reinterpret_cast<uint16_t *>(d2l + o) = f2bf(gsum - bf2f(h));
+    }
+    __syncthreads();
+
+    // ---- conv2 weight gradient: dW2[co][ci][tap] += sum_pix dC2[pix][co] * a1pad[pix + tap][ci] -----
+    {
+      const int t16 = lane & 15, q = t16 >> 2, pq = t16 & 3;
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {  // 121 pixels in 4 k-steps of 32 (rows >= 121 hit a zero halo pixel of dC2)
+        const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
+        const bool v_lo = i_lo < C2N, v_hi = i_hi < C2N;
+        const int y_lo = v_lo ? i_lo / C2W : 0, x_lo = v_lo ? i_lo % C2W : 0;
+        const int y_hi = v_hi ? i_hi / C2W : 0, x_hi = v_hi ? i_hi % C2W : 0;
+        // A: dC2^T, rows = pixels (padded plane index, or halo pixel 0 for dummy rows), 16 co per tile
+        const uint32_t ya_lo = (v_lo ? ((y_lo + 4) * D2PW + x_lo + 4) : 0) * 64 + 8 * (pq & 1) + 16 * (pq >> 1);
+        const uint32_t ya_hi = (v_hi ? ((y_hi + 4) * D2PW + x_hi + 4) : 0) * 64 + 8 * (pq & 1) + 16 * (pq >> 1);
+        bf8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = tr_pair(d2h_a + ya_lo + 32 * i, d2h_a + ya_hi + 32 * i);
+          if (SPLIT == 3) al[i] = tr_pair(d2l_a + ya_lo + 32 * i, d2l_a + ya_hi + 32 * i);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nt = wave + 4 * j;  // N tile = taps 2 nt, 2 nt + 1
+          if (nt < 13) {                // wave-uniform
+            int tap = 2 * nt + (pq >> 1);
+            if (tap > 24) tap = 24;     // the 26th tap does not exist: recompute tap 24, dropped at the end
+            const int toff = (tap / 5) * A1PW + (tap % 5);
+            // B: a1 padded plane [pix][8 ci] (16 B rows): fragment columns 0-7 = tap 2nt, 8-15 = tap 2nt+1
+            const uint32_t xa_lo = ((y_lo * A1PW + x_lo) + toff) * 16 + 8 * (pq & 1);
+            const uint32_t xa_hi = ((y_hi * A1PW + x_hi) + toff) * 16 + 8 * (pq & 1);
+            const bf8 bh = tr_pair(a1h_a + xa_lo, a1h_a + xa_hi);
+            bf8 bl;
+            if (SPLIT == 3) bl = tr_pair(a1l_a + xa_lo, a1l_a + xa_hi);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              if (SPLIT == 3) {
+                wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, wacc[i][j], 0, 0, 0);
+                wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, wacc[i][j], 0, 0, 0);
+              }
+              wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, wacc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- conv2 backward-data: dA1[ya][xa][ci] = sum_{tap,co} dC2[ya - ty + 1][xa - tx + 1][co] W2[co][ci][tap] ----
+    {
+      f32x4 dacc[3];
+      int base[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int i = 16 * (3 * wave + k) + r16;  // 169 pixels -> 11 row tiles (wave 3 has 2)
+        if (i >= A1W * A1W) i = 0;
+        base[k] = ((i / A1W) + 5) * D2PW + (i % A1W) + 5;  // padded dC2 pixel of tap (0,0); tap shifts by -(ty*19 + tx)
+      }
+#pragma unroll 5
+      for (int tap = 0; tap < 25; ++tap) {
+        const int toff = (tap / 5) * D2PW + (tap % 5);
+        // B: backward weights [tap][ci][32 co]: lane (ci = r16, k = co 8g..8g+7); ci >= 8 are zero columns
+        bf8 bh, bl;
+        const s8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+        bh = __builtin_bit_cast(bf8, z);
+        bl = bh;
+        if (r16 < 8) {
+          const int o = ((tap * 8 + r16) * 32 + 8 * g) * 2;
+          bh = *reinterpret_cast<const bf8 *>(wbh + o);
+          if (SPLIT == 3) bl = *reinterpret_cast<const bf8 *>(wbl + o);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (3 * wave + k < 11) {  // wave-uniform
+            const int o = (base[k] - toff) * 64 + 16 * g;
+            const bf8 ah = *reinterpret_cast<const bf8 *>(d2h + o);
+            if (SPLIT == 3) {
+              const bf8 al = *reinterpret_cast<const bf8 *>(d2l + o);
+              dacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, dacc[k], 0, 0, 0);
+              dacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, dacc[k], 0, 0, 0);
+            }
+            dacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, dacc[k], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // dyb (aliased by dA1) and the d2 planes are no longer read by the weight-gradient phase
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (r16 < 8)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * (3 * wave + k) + 4 * g + r;
+            if (3 * wave + k < 11 && i < A1W * A1W) dA1[i * 8 + r16] = dacc[k][r];
+          }
+    }
+    __syncthreads();
+
+    // ---- pool1 + ReLU1 backward -> dC1 [196][8]; then the d2 planes' interior is cleared for the next patch ----
+    for (int e = tid; e < C1N * 8; e += 256) {
+      const int co = e & 7, pix = e >> 3, y = pix / C1W, x = pix % C1W;
+      float gsum = 0.f;
+      if (L.c1r[e] > 0.f) {
+#pragma unroll
+        for (int dyw = 0; dyw < 2; ++dyw)
+#pragma unroll
+          for (int dxw = 0; dxw < 2; ++dxw) {
+            const int wy = y - dyw, wx = x - dxw;
+            if (wy >= 0 && wy < A1W && wx >= 0 && wx < A1W) {
+              const float *s = L.c1r + (wy * C1W + wx) * 8 + co;
+              if (argmax4(s[0], s[8], s[C1W * 8], s[C1W * 8 + 8]) == dyw * 2 + dxw) gsum += dA1[(wy * A1W + wx) * 8 + co];
+            }
+          }
+      }
+      dC1[e] = gsum;
+    }
+    __syncthreads();
+
+    // ---- conv1 weight / bias gradient (VALU): element t = tid (+256) < 8*cin*25 is dW1[co][ci][tap] ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = tid + 256 * h;
+      if (t < 8 * cin * 25) {
+        const int tap = t % 25, ci = (t / 25) % cin, co = t / (25 * cin);
+        const float *xs = L.xs + (ci * XPW + tap / 5) * XPW + tap % 5;
+        float s = 0.f;
+        for (int pix = 0; pix < C1N; ++pix) s = fmaf(dC1[pix * 8 + co], xs[(pix / C1W) * XPW + pix % C1W], s);
+        dw1[h] += s;
+      }
+    }
+    if (tid >= 248) {  // the last 8 threads also own the bias gradient of conv1
+      const int co = tid - 248;
+      float s = 0.f;
+      for (int pix = 0; pix < C1N; ++pix) s += dC1[pix * 8 + co];
+      db1 += s;
+    }
+    __syncthreads();  // next patch may overwrite xs / dyb
+  }
+
+  // ---- partial sums of this slice -> workspace ------------------------------------------------------
+  const int PART = 32 * 8 * 25 + 32 + 8 * cin * 25 + 8;
+  float *out = a.part + (long)blockIdx.x * PART;
+  // wacc[i][j][r] = dW2[co = 16 i + 4 g + r][ci = r16 & 7][tap = 2 (wave + 4 j) + (r16 >> 3)]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tap = 2 * (wave + 4 * j) + (r16 >> 3);
+      if (wave + 4 * j < 13 && tap < 25)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[((16 * i + 4 * g + r) * 8 + (r16 & 7)) * 25 + tap] = wacc[i][j][r];
+    }
+  // db2: thread t summed channel t & 31 over its pixel subset -> reduce the 8 threads per channel through LDS
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(lds);
+  red[tid] = db2;
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f;
+    for (int k = 0; k < 8; ++k) s += red[tid + 32 * k];
+    out[32 * 8 * 25 + tid] = s;
+  }
+  if (tid < 8 * cin * 25) out[32 * 8 * 25 + 32 + tid] = dw1[0];
+  if (tid + 256 < 8 * cin * 25) out[32 * 8 * 25 + 32 + tid + 256] = dw1[1];
+  if (tid >= 248) out[32 * 8 * 25 + 32 + 8 * cin * 25 + (tid - 248)] = db1;
+}
+
+// out[e] = sum_k part[k * stride + e], e < n   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void front_slice_sum_kernel(const float *__restrict__ part, int nslice, int stride,
+                                                              int n, float *__restrict__ out) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += part[(long)k * stride + e];
+    out[e] = s;
+  }
+}
+
+size_t fwd_lds_bytes(int cin) {
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  return r(4 * cin * XPW * XPW) + r(4 * (8 * cin * 25 + 8)) + r(4 * C1N * 8) + 2 * r(A1PW * A1PW * 16) +
+         2 * r(KS2 * 32 * 32 * 2) + r(4 * C2N * 32);
+}
+size_t bwd_lds_bytes(int cin) {
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  return fwd_lds_bytes(cin) + 2 * r(25 * 8 * 32 * 2) + 2 * r(D2PW * D2PW * 64) + r(4 * ON * 32);
+}
+int front_slices(int P) { return P < 512 ? P : 512; }
+
+}  // namespace
+}  // namespace crw
+
+using namespace crw;
+
+extern "C" {
+
+// conv2 weight [32][8][5][5] fp32 -> forward planes [7][32][32] and backward planes [25][8][32] (bf16 hi[, lo])
+int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi, uint16_t *bwd_lo,
+                       crw_stream_t stream) {
+  clear_stale_error();
+  if (!w2 || !fwd_hi || !bwd_hi || (fwd_lo == nullptr) != (bwd_lo == nullptr)) return CRW_EINVAL;
+  hipLaunchKernelGGL(pack_w2_kernel, dim3(28), dim3(256), 0, (hipStream_t)stream, w2, fwd_hi, fwd_lo, bwd_hi, bwd_lo);
+  return check_launch();
+}
+
+int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
+                      const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi, uint16_t *y_lo,
+                      crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !w1 || !b1 || !w2_hi || !b2 || !y_hi || P < 1 || (cin != 1 && cin != 2) || (split != 1 && split != 3))
+    return CRW_EINVAL;
+  if (split == 3 && (!w2_lo || !y_lo)) return CRW_EINVAL;
+  FrontArgs a{x, w1, b1, w2_hi, w2_lo, b2, y_hi, y_lo, P, cin};
+  const size_t lds = fwd_lds_bytes(cin);
+  const int grid = P < 1024 ? P : 1024;
+  if (split == 3) hipLaunchKernelGGL(front_fwd_kernel<3>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(front_fwd_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+size_t crw_enc_front_ws_bytes(int P, int cin) {
+  if (P < 1 || (cin != 1 && cin != 2)) return 0;
+  return (size_t)front_slices(P) * (32 * 8 * 25 + 32 + 8 * cin * 25 + 8) * sizeof(float);
+}
+
+// dy [P][100][32] fp32 -> dw2 [32][8][5][5], db2 [32], dw1 [8][cin][5][5], db1 [8]
+int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
+                      const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const uint16_t *w2b_hi,
+                      const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2, void *ws,
+                      size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !w1 || !b1 || !w2_hi || !b2 || !w2b_hi || !dy || !dw1 || !db1 || !dw2 || !db2 || !ws || P < 1 ||
+      (cin != 1 && cin != 2) || (split != 1 && split != 3))
+    return CRW_EINVAL;
+  if (split == 3 && (!w2_lo || !w2b_lo)) return CRW_EINVAL;
+  if (ws_bytes < crw_enc_front_ws_bytes(P, cin)) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int nslice = front_slices(P), ppb = (P + nslice - 1) / nslice;
+  FrontBwdArgs a{{x, w1, b1, w2_hi, w2_lo, b2, nullptr, nullptr, P, cin}, w2b_hi, w2b_lo, dy, (float *)ws, ppb};
+  const size_t lds = bwd_lds_bytes(cin);
+  static bool attr3 = false, attr1 = false;
+  if (split == 3) {
+    if (!attr3) {
+      if (hipFuncSetAttribute((const void *)front_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess) return CRW_EHIP;
+      attr3 = true;
+    }
+    hipLaunchKernelGGL(front_bwd_kernel<3>, dim3(nslice), dim3(256), lds, s, a);
+  } else {
+    if (!attr1) {
+      if (hipFuncSetAttribute((const void *)front_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess) return CRW_EHIP;
+      attr1 = true;
+    }
+    hipLaunchKernelGGL(front_bwd_kernel<1>, dim3(nslice), dim3(256), lds, s, a);
+  }
+  CRW_TRY(check_launch());
+  const int n2 = 32 * 8 * 25, n1 = 8 * cin * 25, PART = n2 + 32 + n1 + 8;
+  // the partial layout is [dW2 | db2 | dW1 | db1]; the outputs are four separate tensors
+  float *part = (float *)ws;
+  struct Seg { int off, n; float *dst; } segs[4] = {{0, n2, dw2}, {n2, 32, db2}, {n2 + 32, n1, dw1}, {n2 + 32 + n1, 8, db1}};
+  for (auto &sg : segs)
+    hipLaunchKernelGGL(front_slice_sum_kernel, dim3((sg.n + 255) / 256), dim3(256), 0, s, part + sg.off, nslice, PART,
+                       sg.n, sg.dst);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -3,12 +3,12 @@
 so checkpoints are interchangeable and, with the same ``torch.manual_seed``, the initial weights
 are identical (layers are constructed in the same order, so the RNG stream is consumed alike).
 
-Arithmetic: conv1/pool1/conv2/pool2 and the linear head are PyTorch-ROCm ops (3.3 % of the
-encoder's flops).  On an MI355X, for 16x16 patches, the three 3x3 layers conv3/conv4/conv5 (+ReLU)
-and the global average pool -- 96.7 % of the flops, forward AND backward -- run in the hand-written
-implicit-GEMM MFMA kernels of csrc/encoder_conv.hip (``CNN.hip_convs``: "bf16x3" = hi/lo bf16
-operand pairs, fp32-grade results, the default; "bf16" = plain bf16 operands; None = PyTorch ops).
-``Resnet`` is PyTorch-ROCm throughout.
+Arithmetic: on an MI355X, for 16x16 patches, the whole conv trunk of ``CNN`` -- the fused front end
+conv1-ReLU-pool-conv2-ReLU-pool (csrc/encoder_front.hip), the 3x3 layers conv3/conv4/conv5 (+ReLU)
+and the global average pool (csrc/encoder_conv.hip), forward AND backward -- runs in hand-written
+HIP kernels (``CNN.hip_convs``: "bf16x3" = hi/lo bf16 operand pairs on the matrix cores, fp32-grade
+results, the default; "bf16" = plain bf16 operands; None = PyTorch-ROCm ops).  Only the linear
+head stays a PyTorch op.  Other patch sizes, CPU tensors and ``Resnet`` use PyTorch ops throughout.
 """
 import torch
 import torch.nn as nn
@@ -17,21 +17,25 @@ import torch.nn.functional as TF
 FEATURE_DIM = 128
 
 
-class _HipConv345(torch.autograd.Function):
-    """relu(conv5(relu(conv4(relu(conv3(x)))))) followed by the global average pool, on the HIP kernels.
-    x: [P,32,10,10] fp32 (output of pool2) -> [P,128] fp32."""
+class _HipEncoder(torch.autograd.Function):
+    """The whole conv trunk of ``CNN`` on the HIP kernels: fused front end (conv1-ReLU-pool-conv2-ReLU-
+    pool), conv3/conv4/conv5 (+ReLU) and the global average pool.  x [P,cin,16,16] fp32 -> [P,128] fp32.
+    Saved for backward: the input patches and the bf16 activation planes of conv2..conv5 outputs
+    (the front end is recomputed in its backward kernel)."""
 
     @staticmethod
-    def forward(ctx, x, w3, b3, w4, b4, w5, b5, split):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, split):
         import crw_hip
+        x = x.contiguous()
+        w2p = crw_hip.enc_front_pack(w2, split)
         packed = [crw_hip.enc_pack_weights(w, split) for w in (w3, w4, w5)]
-        x3h, x3l = crw_hip.enc_pack_input(x, split)
+        x3h, x3l = crw_hip.enc_front_fwd(split, x, w1, b1, w2p[:2], b2)
         y3h, y3l, _, _ = crw_hip.enc_conv3x3(0, split, x3h, x3l, packed[0][0], packed[0][1], 64, bias=b3)
         y4h, y4l, _, _ = crw_hip.enc_conv3x3(0, split, y3h, y3l, packed[1][0], packed[1][1], 128, bias=b4)
         y5h, _, _, gap = crw_hip.enc_conv3x3(0, split, y4h, y4l, packed[2][0], packed[2][1], 128, bias=b5, gap=True,
                                              lo_plane=False)  # only the sign of y5 is needed later
         ctx.split = split
-        ctx.planes = (x3h, x3l, y3h, y3l, y4h, y4l, y5h)
+        ctx.saved = (x, w1.detach(), b1.detach(), b2.detach(), w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h)
         ctx.bwd_w = [(pk[2], pk[3]) for pk in packed]
         return gap
 
@@ -39,7 +43,7 @@ class _HipConv345(torch.autograd.Function):
     def backward(ctx, dgap):
         import crw_hip
         s = ctx.split
-        x3h, x3l, y3h, y3l, y4h, y4l, y5h = ctx.planes
+        x, w1, b1, b2, w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h = ctx.saved
         # dY5 = dgap/100 gated by y5 > 0 (ReLU5 + GAP backward) is built inside the two kernels' loaders
         dgap = dgap.contiguous().float()
         dw5, db5 = crw_hip.enc_wgrad(s, y5h, None, y4h, y4l, dgap=dgap)
@@ -47,11 +51,10 @@ class _HipConv345(torch.autograd.Function):
         dw4, db4 = crw_hip.enc_wgrad(s, d4h, d4l, y3h, y3l)
         d3h, d3l, _, _ = crw_hip.enc_conv3x3(1, s, d4h, d4l, *ctx.bwd_w[1], 64, mask=y3h)    # dY3
         dw3, db3 = crw_hip.enc_wgrad(s, d3h, d3l, x3h, x3l)
-        _, _, dx, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *ctx.bwd_w[0], 32, planes=False, f32=True)
-        ctx.planes = None
-        P = dx.shape[0]
-        dx = dx.view(P, 10, 10, 32).permute(0, 3, 1, 2).contiguous()  # NCHW like the forward input
-        return dx, dw3, db3, dw4, db4, dw5, db5, None
+        _, _, dx3, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *ctx.bwd_w[0], 32, planes=False, f32=True)  # [P,100,32]
+        dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3)
+        ctx.saved = None
+        return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
 # (name, out_channels, kernel, followed by 2x2/stride-1 max-pool?)
 _CNN_STACK = (("1", 8, 5, True), ("2", 32, 5, True), ("3", 64, 3, False), ("4", 128, 3, False), ("5", 128, 3, False))
@@ -83,10 +86,10 @@ class CNN(nn.Module):
 
     def forward(self, x):
         if self.hip_convs and x.is_cuda and x.shape[-2:] == (16, 16) and x.dtype == torch.float32:
-            x = self.pool1(self.relu1(self.conv1(x)))
-            x = self.pool2(self.relu2(self.conv2(x)))  # [P,32,10,10]
-            gap = _HipConv345.apply(x, self.conv3.weight, self.conv3.bias, self.conv4.weight, self.conv4.bias,
-                                    self.conv5.weight, self.conv5.bias, 3 if self.hip_convs == "bf16x3" else 1)
+            c = [getattr(self, "conv%d" % i) for i in range(1, 6)]
+            gap = _HipEncoder.apply(x, c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[2].weight, c[2].bias,
+                                    c[3].weight, c[3].bias, c[4].weight, c[4].bias,
+                                    3 if self.hip_convs == "bf16x3" else 1)
             return self.fc(gap)
         for name, _, _, pooled in _CNN_STACK:
             x = getattr(self, "relu" + name)(getattr(self, "conv" + name)(x))

@@ -243,6 +243,35 @@ def test_encoder_conv_kernels_match_torch(hip, cin, cout, split):
     torch.testing.assert_close(db.cpu().double(), dyq.sum((0, 2, 3)), **wtol)
 
 
+@pytest.mark.parametrize("cin", [1, 2])
+@pytest.mark.parametrize("split", [3, 1])
+def test_encoder_front_kernels_match_torch(hip, cin, split):
+    """fused conv1-ReLU-pool-conv2-ReLU-pool forward and its backward against fp64 torch autograd."""
+    import torch.nn.functional as TF
+    P = 7
+    g = torch.Generator().manual_seed(10 * cin + split)
+    x = torch.randn(P, cin, 16, 16, generator=g)
+    w1 = (torch.randn(8, cin, 5, 5, generator=g) * 0.2).double().requires_grad_(True)
+    b1 = (torch.randn(8, generator=g) * 0.1).double().requires_grad_(True)
+    w2 = (torch.randn(32, 8, 5, 5, generator=g) * 0.07).double().requires_grad_(True)
+    b2 = (torch.randn(32, generator=g) * 0.1).double().requires_grad_(True)
+    a1 = TF.max_pool2d(TF.relu(TF.conv2d(x.double(), w1, b1, padding=1)), 2, 1)
+    y = TF.max_pool2d(TF.relu(TF.conv2d(a1, w2, b2, padding=1)), 2, 1)  # [P,32,10,10]
+    dy = torch.randn(P, 100, 32, generator=g)
+    y.backward(dy.double().reshape(P, 10, 10, 32).permute(0, 3, 1, 2))
+    c = lambda t: t.detach().float().cuda()
+    w2f = hip.enc_front_pack(c(w2), split)
+    yh, yl = hip.enc_front_fwd(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2))
+    tol = dict(rtol=1e-4, atol=1e-4) if split == 3 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(_planes_value(yh, yl).cpu().double(), _to_planes_ref(y.detach()), **tol)
+    dw1, db1, dw2, db2 = hip.enc_front_bwd(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2), w2f[2:], dy.cuda())
+    for got, ref in ((dw2, w2.grad), (db2, b2.grad), (dw1, w1.grad), (db1, b1.grad)):
+        # plain bf16: rounding conv2's inputs can flip a max-pool arg-max, which re-routes a gradient
+        t = dict(rtol=2e-3, atol=2e-3 * ref.abs().max().item()) if split == 3 else \
+            dict(rtol=2e-1, atol=1.5e-1 * ref.abs().max().item())
+        torch.testing.assert_close(got.cpu().double(), ref, **t)
+
+
 LP_CASES = ["labelprop_trunc_T14N10", "labelprop_full_T40N48", "labelprop_last_T20N24", "labelprop_mc1_T100N12"]
 
 
