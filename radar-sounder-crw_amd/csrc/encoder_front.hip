@@ -522,7 +522,7 @@ size_t bwd_lds_bytes(int cin) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
   return fwd_lds_bytes(cin) + 2 * r(25 * 8 * 32 * 2) + 2 * r(D2PW * D2PW * 64) + r(4 * ON * 32);
 }
-int front_slices(int P) { return P < 512 ? P : 512; }
+int front_slices(int P) { return P < 256 ? P : 256; }  // one 144 KB workgroup per CU
 
 }  // namespace
 }  // namespace crw
