@@ -142,41 +142,41 @@ struct ConvArgs {
   int P;
 };
 
-// PPW patches per workgroup (PPW x 4 waves): the wave groups run the same weight stream on different
-// patches side by side, so their identical weight-fragment requests meet in the CU's L1 / miss
-// queue and the L2 sees them once -- the kernel is bound by weight bytes per CU, not by MFMA issue.
+// PPW patches per workgroup, processed by the SAME four waves: every weight fragment a wave pulls
+// from L2 feeds the row tiles of PPW patches (PPW x 7 x NTW x SPLIT MFMAs per 16-byte-per-lane
+// load).  PPW = 1 is what ships (see launch_conv).
 template <int SPLIT, int CIN, int COUT, int MODE, int PPW>
-__global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
   constexpr int PLANE = plane_bytes<CMAX>();  // bytes per LDS plane (input image, later output staging)
+  constexpr int PATCH = NPL * PLANE;          // LDS bytes per patch
   constexpr int WN = (COUT / 16 >= 4) ? 4 : COUT / 16;  // waves across the output channels
   constexpr int WM = 4 / WN;                            // waves across the pixel row tiles
   constexpr int NTW = COUT / 16 / WN;                   // 16-wide column tiles per wave
-  constexpr int MTW = (MT + WM - 1) / WM;               // row tiles per wave (tile wm + WM*k)
+  constexpr int MTW = (MT + WM - 1) / WM;               // row tiles per wave and patch (tile wm + WM*k)
   constexpr int KCH = CIN / 32;                         // 32-deep k-steps per tap
-  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  extern __shared__ __attribute__((aligned(16))) char lds[];
 
-  const int half = threadIdx.x / 256;            // which patch of this workgroup
-  int p = blockIdx.x * PPW + half;
-  const bool live = p < a.P;                     // a tail workgroup may hold a spare wave group:
-  if (!live) p = a.P - 1;                        // it recomputes the last patch and writes nothing
-  char *lds = lds_all + half * (NPL * PLANE);
-  const int tid = threadIdx.x % 256, lane = tid & 63, wave = tid >> 6;
+  const int p0 = blockIdx.x * PPW;  // patches p0 .. p0+PPW-1 (a tail workgroup recomputes the last patch, writes nothing)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
 
-  // ---- patch -> LDS ------------------------------------------------------------------------------
-  {
-    zero_halo<CIN, 256>(lds, tid);
-    if (SPLIT == 3) zero_halo<CIN, 256>(lds + PLANE, tid);
+  // ---- patches -> LDS ----------------------------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int p = min(p0 + q, a.P - 1);
+    char *img = lds + q * PATCH;
+    zero_halo<CIN, 256>(img, tid);
+    if (SPLIT == 3) zero_halo<CIN, 256>(img + PLANE, tid);
     if (MODE == 1 && a.dgap) {
-      gap_planes_to_lds<CIN, 256, SPLIT>(a.xh + (long)p * NPIX * CIN, a.dgap + (long)p * CIN, lds, lds + PLANE, tid);
+      gap_planes_to_lds<CIN, 256, SPLIT>(a.xh + (long)p * NPIX * CIN, a.dgap + (long)p * CIN, img, img + PLANE, tid);
     } else {
       PlaneLoad<CIN, 256> lh, ll;
       lh.load(a.xh + (long)p * NPIX * CIN, tid);
       if (SPLIT == 3) ll.load(a.xl + (long)p * NPIX * CIN, tid);
-      lh.store(lds, tid);
-      if (SPLIT == 3) ll.store(lds + PLANE, tid);
+      lh.store(img, tid);
+      if (SPLIT == 3) ll.store(img + PLANE, tid);
     }
   }
   __syncthreads();
@@ -191,11 +191,13 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
     pp0[k] = (i / IMG_W) * PAD_W + (i % IMG_W);
   }
 
-  f32x4 acc[MTW][NTW];
+  f32x4 acc[PPW][MTW][NTW];
 #pragma unroll
-  for (int k = 0; k < MTW; ++k)
+  for (int q = 0; q < PPW; ++q)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < MTW; ++k)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[q][k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int co_w = wn * (16 * NTW);  // first output channel of this wave
   auto load_b = [&](int step, bf8 (&bh)[NTW], bf8 (&bl)[NTW]) {
@@ -209,28 +211,31 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
   };
 
   constexpr int NSTEP = 9 * KCH;
-  constexpr int AHEAD = 3;  // weight fragments are requested 3 k-steps (~2k cycles) before use: L2 latency under load
+  constexpr int AHEAD = 3;  // weight fragments are requested 3 k-steps before use: L2 latency under load
   auto do_step = [&](int step, bf8 (&bhc)[NTW], bf8 (&blc)[NTW], bf8 (&bhn)[NTW], bf8 (&bln)[NTW]) {
     if (step + AHEAD < NSTEP) load_b(step + AHEAD, bhn, bln);
     const int tap = step / KCH, cc = step % KCH;
     const int toff = (tap / 3) * PAD_W + (tap % 3);
 #pragma unroll
-    for (int k = 0; k < MTW; ++k) {
-      if (WM == 1 || wm + WM * k < MT) {  // wave-uniform
-        const int pp = pp0[k] + toff;
-        const bf8 ah = *reinterpret_cast<const bf8 *>(lds + px_off<CIN>(pp, 4 * cc + g));
-        bf8 al;
-        if (SPLIT == 3) al = *reinterpret_cast<const bf8 *>(lds + PLANE + px_off<CIN>(pp, 4 * cc + g));
+    for (int q = 0; q < PPW; ++q)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          if (SPLIT == 3) {
-            acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhc[j], acc[k][j], 0, 0, 0);
-            acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blc[j], acc[k][j], 0, 0, 0);
+      for (int k = 0; k < MTW; ++k) {
+        if (WM == 1 || wm + WM * k < MT) {  // wave-uniform
+          const int pp = pp0[k] + toff;
+          const char *img = lds + q * PATCH;
+          const bf8 ah = *reinterpret_cast<const bf8 *>(img + px_off<CIN>(pp, 4 * cc + g));
+          bf8 al;
+          if (SPLIT == 3) al = *reinterpret_cast<const bf8 *>(img + PLANE + px_off<CIN>(pp, 4 * cc + g));
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            if (SPLIT == 3) {
+              acc[q][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhc[j], acc[q][k][j], 0, 0, 0);
+              acc[q][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blc[j], acc[q][k][j], 0, 0, 0);
+            }
+            acc[q][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhc[j], acc[q][k][j], 0, 0, 0);
           }
-          acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhc[j], acc[k][j], 0, 0, 0);
         }
       }
-    }
   };
   // four register sets for the weight fragments, rotated with static indices (a run-time index
   // would send them to scratch): step s uses set s % 4 and refills set (s + 3) % 4
@@ -250,82 +255,93 @@ __global__ __launch_bounds__(256 * PPW) void conv3x3_kernel(ConvArgs a) {
   if (NSTEP % 4 >= 3) do_step(step + 2, bh2, bl2, bh1, bl1);
 
   // ---- epilogue ----------------------------------------------------------------------------------
-  // C/D map: acc[k][j][r] = out[pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
-  float gsum[NTW], bias_r[NTW];
+  // C/D map: acc[q][k][j][r] = out[patch p0+q][pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
+  float bias_r[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    gsum[j] = 0.f;
-    bias_r[j] = (MODE == 0 && a.bias) ? a.bias[co_w + 16 * j + r16] : 0.f;
-  }
-  __syncthreads();  // every wave is done reading the input image: reuse LDS as the output staging
+  for (int j = 0; j < NTW; ++j) bias_r[j] = (MODE == 0 && a.bias) ? a.bias[co_w + 16 * j + r16] : 0.f;
+  __syncthreads();  // every wave is done reading the input images: reuse LDS as the output staging
 #pragma unroll
-  for (int k = 0; k < MTW; ++k)
+  for (int q = 0; q < PPW; ++q) {
+    const int p = p0 + q;
+    const bool live = p < a.P;
+    char *img = lds + q * PATCH;
+    float gsum[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int co = co_w + 16 * j + r16;
+    for (int j = 0; j < NTW; ++j) gsum[j] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * (wm + WM * k) + 4 * g + r;
-        if (i < NPIX) {
-          const int pp = (i / IMG_W + 1) * PAD_W + (i % IMG_W + 1);
-          float v = acc[k][j][r];
-          if (MODE == 0) {
-            v = fmaxf(v + bias_r[j], 0.f);
-            gsum[j] += v;
-          }
-          if (a.yf && live) a.yf[((long)p * NPIX + i) * COUT + co] = v;
-          if (a.yh) {
-            const uint16_t h = f2bf(v);
-            *reinterpret_cast<uint16_t *>(lds + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = h;
-            if (SPLIT == 3 && a.yl)
-              *reinterpret_cast<uint16_t *>(lds + PLANE + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = f2bf(v - bf2f(h));
+    for (int k = 0; k < MTW; ++k)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int co = co_w + 16 * j + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * (wm + WM * k) + 4 * g + r;
+          if (i < NPIX) {
+            const int pp = interior_pp(i);
+            float v = acc[q][k][j][r];
+            if (MODE == 0) {
+              v = fmaxf(v + bias_r[j], 0.f);
+              gsum[j] += v;
+            }
+            if (a.yf && live) a.yf[((long)p * NPIX + i) * COUT + co] = v;
+            if (a.yh) {
+              const uint16_t h = f2bf(v);
+              *reinterpret_cast<uint16_t *>(img + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = h;
+              if (SPLIT == 3 && a.yl)
+                *reinterpret_cast<uint16_t *>(img + PLANE + px_off<COUT>(pp, co >> 3) + 2 * (co & 7)) = f2bf(v - bf2f(h));
+            }
           }
         }
       }
-    }
-  if (MODE == 0 && WM == 1 && a.gap) {
+    if (MODE == 0 && WM == 1 && a.gap) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      float s = gsum[j];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (g == 0 && live) a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
+      for (int j = 0; j < NTW; ++j) {
+        float s = gsum[j];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0 && live) a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
+      }
     }
   }
   if (a.yh) {
     __syncthreads();
-    // staged tile -> global in whole 16-byte chunks; the ReLU mask of the layer below (MODE 1) is
+    // staged tiles -> global in whole 16-byte chunks; the ReLU mask of the layer below (MODE 1) is
     // applied here, 8 channels at a time, from the matching chunk of its activation plane
     constexpr int NCH = COUT / 8, TOTAL = NPIX * NCH, ITER = (TOTAL + 255) / 256;
-    const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (long)p * NPIX * COUT : nullptr;
-    uint4 mv[ITER];
-    if (mk) {
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int c = tid + it * 256;
-        if (c < TOTAL) mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
+    for (int q = 0; q < PPW; ++q) {
+      const int p = p0 + q;
+      if (p >= a.P) break;
+      const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (long)p * NPIX * COUT : nullptr;
+      uint4 mv[ITER];
+      if (mk) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int c = tid + it * 256;
+          if (c < TOTAL) mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
+        }
       }
-    }
-    for (int pl = 0; pl < NPL; ++pl) {
-      if (pl && !a.yl) break;  // the lo plane is optional (nobody reads conv5's)
-      uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPIX * COUT;
-      const char *src = lds + pl * PLANE;
+      for (int pl = 0; pl < NPL; ++pl) {
+        if (pl && !a.yl) break;  // the lo plane is optional (nobody reads conv5's)
+        uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPIX * COUT;
+        const char *src = lds + q * PATCH + pl * PLANE;
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int c = tid + it * 256;
-        if (c < TOTAL) {
-          uint4 v = *reinterpret_cast<const uint4 *>(src + px_off<COUT>(interior_pp(c / NCH), c % NCH));
-          if (mk) {  // keep a bf16 lane only where the mask lane is non-zero
-            const uint32_t m[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
-            uint32_t o[4] = {v.x, v.y, v.z, v.w};
+        for (int it = 0; it < ITER; ++it) {
+          const int c = tid + it * 256;
+          if (c < TOTAL) {
+            uint4 v = *reinterpret_cast<const uint4 *>(src + px_off<COUT>(interior_pp(c / NCH), c % NCH));
+            if (mk) {  // keep a bf16 lane only where the mask lane is non-zero
+              const uint32_t m[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
+              uint32_t o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const uint32_t keep = ((m[w] & 0x7fffu) ? 0xffffu : 0u) | ((m[w] & 0x7fff0000u) ? 0xffff0000u : 0u);
-              o[w] &= keep;
+              for (int w = 0; w < 4; ++w) {
+                const uint32_t keep = ((m[w] & 0x7fffu) ? 0xffffu : 0u) | ((m[w] & 0x7fff0000u) ? 0xffff0000u : 0u);
+                o[w] &= keep;
+              }
+              v = uint4{o[0], o[1], o[2], o[3]};
             }
-            v = uint4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<uint4 *>(dst + (long)c * 8) = v;
           }
-          if (live) *reinterpret_cast<uint4 *>(dst + (long)c * 8) = v;
         }
       }
     }
@@ -581,10 +597,9 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ 
   }
 }
 
-template <int SPLIT, int CIN, int COUT, int MODE>
-int launch_conv(const ConvArgs &a, hipStream_t s) {
+template <int SPLIT, int CIN, int COUT, int MODE, int PPW>
+int launch_conv_ppw(const ConvArgs &a, hipStream_t s) {
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
-  constexpr int PPW = 1;  // 2 (one 512-thread workgroup, two patches) measured 15-20 % slower than two independent workgroups
   const size_t lds = (size_t)PPW * (SPLIT == 3 ? 2 : 1) * plane_bytes<CMAX>();
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
@@ -595,9 +610,17 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256 * PPW), lds,
-                     s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256), lds, s, a);
   return check_launch();
+}
+
+template <int SPLIT, int CIN, int COUT, int MODE>
+int launch_conv(const ConvArgs &a, hipStream_t s) {
+  // PPW = 2 (each weight fragment feeds two patches, one 4-wave workgroup per CU) was measured 20-30 %
+  // SLOWER than PPW = 1 with two independent workgroups per CU on every layer (conv5 fwd 2.19 vs 1.73 ms):
+  // overlapping one workgroup's load/store phases with the other's MFMAs is worth more than the
+  // halved weight stream.  The template parameter stays for that A/B.
+  return launch_conv_ppw<SPLIT, CIN, COUT, MODE, 1>(a, s);
 }
 
 // input channels per workgroup: 64 keeps 9 taps x 4 ci tiles = 144 accumulator registers per lane
