@@ -332,6 +332,20 @@ def main():
                             "frac": pfl / (pms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], "traffic": None,
                             "launch_us": pms * 1e3, "shape": f"n={Np} batch={B}x3",
                             "note": "launch-latency bound at the reference-default node count"})
+            # HBM traffic from the committed PMC pass (profiles/r01_pmc_conv5.json; rocprofv3 cannot run inside bench)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))["kernels"]
+                for k in kernels:
+                    if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
+                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64>" if "wgrad" in k["kernel"] else
+                               "conv3x3_kernel<3, 128, 128, 1, 1>" if "bwd-data" in k["kernel"] else
+                               "conv3x3_kernel<3, 128, 128, 0, 1>")
+                        k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + pmc[key]["algorithmic_write_bytes"]
+                        k["traffic_note"] = ("HBM read bytes = 2*1024*FETCH_SIZE (gfx950 correction) from the committed PMC pass "
+                                             "+ algorithmic write bytes (WRITE_SIZE is polluted by the previous dispatch's write-back); "
+                                             f"read/algorithmic = {pmc[key]['read_over_algorithmic']}, L2 hit rate {pmc[key]['l2_hit_rate']}")
+            except Exception:
+                pass
             # the dominant kernel of the timed step = the hand-written kernel with the largest time per step
             dom = max((k for k in kernels if "launches_per_step" in k), key=lambda k: k["launch_us"], default=kernels[-1])
             out["roofline"] = dom
