@@ -355,7 +355,7 @@ struct WgradArgs {
   const uint16_t *dyh, *dyl;  // [P][100][COUT] masked output gradient planes
   const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
   const float *dgap;          // optional [P][COUT]: dY = dgap/100 gated by dyh (= forward activation hi plane)
-  float *dw_part;             // [nslice][COUT][CIN][3][3] fp32 partial sums (every element written)
+  float *dw_part;             // [nslice][9 taps][COUT][CIN] fp32 partial sums (every element written)
   float *db_part;             // [nslice][CIN/NCI][COUT] fp32 partial sums
   int P, patches_per_block;
 };
@@ -520,7 +520,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 
   // partial sums of this patch slice -> workspace (plain stores; a second kernel adds the slices
   // in a fixed order, so gradients are bitwise reproducible and no float atomics are needed).
-  // acc[tap][j][r] = dW[co0 + 4 g + r][ci_base + 16 (nt0 + j) + lane&15][tap]
+  // acc[tap][j][r] = dW[co0 + 4 g + r][ci_base + 16 (nt0 + j) + lane&15][tap]; the partial slab is laid out
+  // [tap][co][ci] so that the 16 lanes of a fragment row store 64 contiguous bytes (a [co][ci][tap]
+  // slab makes every 4-byte store its own HBM transaction: PMC WRITE_SIZE was 20x the slab size)
   float *dwp = a.dw_part + (long)blockIdx.y * COUT * CIN * 9;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + 4 * g + r, ci = ci_base + 16 * (nt0 + j) + (lane & 15);
-        dwp[((long)co * CIN + ci) * 9 + tap] = acc[tap][j][r];
+        dwp[((long)tap * COUT + co) * CIN + ci] = acc[tap][j][r];
       }
   // bias partials: reduce the 512/COUT pixel parts of each channel through LDS
   __syncthreads();
@@ -550,6 +552,18 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float *__restrict_
     float s = 0.f;
     for (int k = 0; k < nslice; ++k) s += part[(long)k * n + e];
     out[e] = s;
+  }
+}
+
+// same for the weight gradient: slabs are [tap][co*ci], the result is the framework layout [co*ci][tap]
+__global__ __launch_bounds__(256) void slice_sum_dw_kernel(const float *__restrict__ part, int nslice, int coci,
+                                                           float *__restrict__ out) {
+  const long n = 9L * coci;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += part[(long)k * n + e];
+    const int tap = e / coci, cc = e % coci;
+    out[(long)cc * 9 + tap] = s;
   }
 }
 
@@ -741,7 +755,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
 #undef CRW_WG_CASE
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
-  hipLaunchKernelGGL(slice_sum_kernel, dim3(ew_grid(nw)), dim3(256), 0, s, dw_part, nslice, nw, dw);
+  hipLaunchKernelGGL(slice_sum_dw_kernel, dim3(ew_grid(nw)), dim3(256), 0, s, dw_part, nslice, cout * cin, dw);
   hipLaunchKernelGGL(slice_sum_kernel, dim3(1), dim3(256), 0, s, db_part, nslice * wgrad_groups(cin), (long)cout, db);
   return check_launch();
 }
