@@ -42,9 +42,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain"],
+    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop"],
                     help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
-                         "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder")
+                         "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder; labelprop: BASELINE "
+                         "config 5, MCoRDS-shaped 410x8192 radargram, user-seed label propagation (utils.propagate)")
     ap.add_argument("--nodes", type=int, default=4096, help="N of the chain workload")
     ap.add_argument("--walk", type=int, default=32, help="T (frames) of the chain workload")
     return ap.parse_args()
@@ -237,8 +238,82 @@ def bench_chain(args):
           flush=True)
 
 
+def bench_labelprop(args):
+    """BASELINE config 5: 410x8192 radargram, 32x32 patches, overlap (24,0) -> [T,N] = [256,48]; labels of the
+    first patch column propagated along-track (CXT_SIZE 80 -> exercises the truncation quirk, RADIUS 10,
+    TEMP 0.1, KNN 20, test_all.py defaults).  Metric: label-map columns per second; CPU leg = the oracle."""
+    import numpy as np
+    import dataset as crw_dataset
+    import encoder as crw_encoder
+    import utils as crw_utils
+    from imported.labelprop import LabelPropVOS_CRW
+    from oracle import crw_oracle as orc
+    H, W, T, M = 410, 8192, 256, 4
+    ds = crw_dataset.RGDataset.synthetic(H, W, T, (32, 32), (24, 0), seed=11)
+    seq = ds[0].cuda()
+    N = seq.shape[1]
+    rows = N * 8 + 24
+    seg = (torch.arange(rows)[:, None] * M // rows).float().repeat(1, 32).cuda()
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False).cuda().eval()
+    cfg = dict(CXT_SIZE=80, RADIUS=10, TEMP=0.1, KNN=20)
+
+    def run():
+        return crw_utils.propagate(seq, seg, enc, LabelPropVOS_CRW(cfg), M, False, False)
+
+    for _ in range(max(1, args.warmup)):
+        pred, xent, _ = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred, xent, _ = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # label propagation alone (features resident), the part the HIP kernels own
+    with torch.no_grad():
+        feats = crw_hip_normalize(enc, seq, T, N)
+    lp = LabelPropVOS_CRW(cfg)
+    seed = crw_utils.seed_labels(seg, N)
+    for _ in range(2):
+        lp.propagate_all(feats, seed, M)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        p2, _ = lp.propagate_all(feats, seed, M)
+    torch.cuda.synchronize()
+    dlp = (time.perf_counter() - t1) / args.steps
+    # CPU oracle on the same features (bounded: one pass)
+    emb = feats.cpu().numpy()
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    tc = time.time()
+    ref = orc.labelprop(emb, seed.cpu().numpy(), M, cfg["CXT_SIZE"], cfg["RADIUS"], cfg["TEMP"], cfg["KNN"])
+    dcpu = time.time() - tc
+    match = float((p2.cpu().numpy() == ref).mean())
+    print(json.dumps({"metric": "label-map columns/sec (user-seed label propagation)", "value": W / dt, "unit": "radargram columns/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                      "data": "synthetic", "dtype": "f32",
+                      "config": {"workload": f"{H}x{W} radargram, 32x32 patches overlap (24,0) -> [T,N]=[{T},{N}], {cfg}, "
+                                             "CNN encoder (PyTorch-ROCm ops at this patch size) + normalise + xent + top-k + gather"},
+                      "labelprop_only": {"ms": dlp * 1e3, "columns_per_s": W / dlp,
+                                         "what": "crw_labelprop_topk + crw_labelprop_gather, features resident"},
+                      "cpu_baseline": {"value": W / dcpu, "unit": "radargram columns/s", "kind": "port", "cores": torch.get_num_threads(),
+                                       "sample": f"oracle labelprop (numpy) on the same features, one pass, {dcpu:.2f} s"},
+                      "label_agreement_with_oracle": match}), flush=True)
+
+
+def crw_hip_normalize(enc, seq, T, N):
+    import crw_hip
+    H, W = seq.shape[-2:]
+    emb = enc(seq.reshape(-1, H, W).unsqueeze(1)).reshape(T, N, -1).float().contiguous()
+    return crw_hip.normalize(emb)
+
+
 def main():
     args = parse()
+    if args.workload == "labelprop":
+        import crw_hip
+        crw_hip.lib()
+        return bench_labelprop(args)
     if args.workload == "chain":
         import crw_hip
         crw_hip.lib()

@@ -337,6 +337,51 @@ def test_labelprop_matches_oracle_mcords_shape(hip):
     assert mism == 0, f"{mism} of {ref.size} labels differ"
 
 
+def test_bidirectional_segmentation_pipeline_matches_oracle(hip):
+    """forward pass + reversed pass (use_last) + class-2 merge over two radargram items, checked
+    against the same pipeline restated with the CPU oracle (scripts/test/test_all.py:91-159)."""
+    import dataset as crw_dataset
+    import inference as crw_inference
+    from imported.labelprop import LabelPropVOS_CRW
+    T, h, w, oh, M = 6, 8, 8, 4, 3
+    rg = crw_dataset.synthetic_radargram(44, 2 * T * w, seed=5)
+    ds = crw_dataset.RGDataset.from_tensor(rg, T, (h, w), (oh, 0))
+    N = ds[0].shape[1]
+    rows = N * (h - oh) + oh
+    seg = torch.zeros(rows, rg.shape[1])
+    for r in range(rows):
+        seg[r] = float(min(M - 1, r * M // rows))
+    seg[rows // 2:, T * w:] = 2.0  # second radargram: bedrock lower half, so the reverse merge has work to do
+    enc = _Flatten()
+    cfg = dict(CXT_SIZE=3, RADIUS=3, TEMP=0.1, KNN=4)
+    out = crw_inference.segment(ds, seg, enc, LabelPropVOS_CRW(cfg), M, T, (h, w), (oh, 0), use_last=True, dataset_id=0)
+    rg_len = T * w
+
+    def oracle_pass(item, seg_ref, reverse):
+        emb = item.reshape(T, N, -1).numpy()
+        if reverse:
+            emb = emb[::-1].copy()
+        seed = orc.seed_labels(seg_ref.numpy(), N)
+        pred = orc.labelprop(emb, seed, M, cfg["CXT_SIZE"], cfg["RADIUS"], cfg["TEMP"], cfg["KNN"])
+        ri = np.floor(np.arange(rows) * (N / rows)).astype(int)
+        ci = np.floor(np.arange(rg_len) * (T / rg_len)).astype(int)
+        return pred[ri][:, ci]
+
+    fwd, rev = [], []
+    seg_rev = torch.flip(seg.unfold(1, rg_len, rg_len), (-1,)).reshape(rows, -1)
+    for t, i in enumerate(range(0, len(ds), T)):
+        fwd.append(oracle_pass(ds[i], seg[:rows, rg_len * t:rg_len * t + w], False))
+        rev.append(oracle_pass(ds[i], seg_rev[:rows, rg_len * t:rg_len * t + w], True))
+    fwd = np.concatenate(fwd, 1)
+    rev = np.concatenate([r[:, ::-1] for r in rev], 1)
+    ref = fwd.copy()
+    ref[rev == 2] = 2
+    got = out["pred"].cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} of {ref.size} pixels differ"
+    assert (rev == 2).any() and (fwd != ref).any()  # the merge really changed something
+
+
 def test_no_cpu_fallback(hip):
     import model as crw_model
     with pytest.raises(RuntimeError):
