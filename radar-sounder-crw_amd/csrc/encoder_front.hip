@@ -35,6 +35,8 @@ constexpr int C2W = 11, C2N = C2W * C2W;   // conv2 output 11x11 (121)
 constexpr int OW = 10, ON = 100;           // pool2 output
 constexpr int D2PW = 19;                   // conv2-output gradient padded by 4 (for backward-data)
 constexpr int KS2 = 7;                     // conv2 k-steps (28 taps, 25 real)
+constexpr int NTH = 1024, NWV = NTH / 64;  // 16 waves per workgroup: the stage is LDS-latency bound, one
+                                           // 144 KB workgroup per CU, so latency is hidden by waves, not by workgroups
 
 struct FrontArgs {
   const float *x;            // [P][cin][16][16]
@@ -56,35 +58,34 @@ struct FwdLds {
 };
 
 __device__ inline void load_patch(const float *__restrict__ x, int cin, float *xs, int tid) {
-  for (int e = tid; e < cin * 256; e += 256) {
+  for (int e = tid; e < cin * 256; e += NTH) {
     const int c = e >> 8, r = (e >> 4) & 15, col = e & 15;
     xs[(c * XPW + r + 1) * XPW + col + 1] = x[e];
   }
 }
 
-// conv1 + bias + ReLU: thread = output pixel (196 of 256 threads), all 8 channels
+// conv1 + bias + ReLU: thread = (output pixel, channel pair): 196 x 4 of the 1024 threads
 __device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
-  if (tid < C1N) {
-    const int y = tid / C1W, xx = tid % C1W;
-    float acc[8];
-#pragma unroll
-    for (int co = 0; co < 8; ++co) acc[co] = L.w1[8 * cin * 25 + co];
+  if (tid < C1N * 4) {
+    const int pix = tid >> 2, c0 = 2 * (tid & 3);
+    const int y = pix / C1W, xx = pix % C1W;
+    float acc0 = L.w1[8 * cin * 25 + c0], acc1 = L.w1[8 * cin * 25 + c0 + 1];
     for (int ci = 0; ci < cin; ++ci)
 #pragma unroll
       for (int t = 0; t < 25; ++t) {
         const float v = L.xs[(ci * XPW + y + t / 5) * XPW + xx + t % 5];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, L.w1[(co * cin + ci) * 25 + t], acc[co]);
+        acc0 = fmaf(v, L.w1[(c0 * cin + ci) * 25 + t], acc0);
+        acc1 = fmaf(v, L.w1[((c0 + 1) * cin + ci) * 25 + t], acc1);
       }
-#pragma unroll
-    for (int co = 0; co < 8; ++co) L.c1r[tid * 8 + co] = fmaxf(acc[co], 0.f);
+    L.c1r[pix * 8 + c0] = fmaxf(acc0, 0.f);
+    L.c1r[pix * 8 + c0 + 1] = fmaxf(acc1, 0.f);
   }
 }
 
 // maxpool 2x2/1 of c1r -> a1 planes (interior of the 15x15 padded image)
 template <int SPLIT>
 __device__ inline void pool1(const FwdLds &L, int tid) {
-  for (int e = tid; e < A1W * A1W * 8; e += 256) {
+  for (int e = tid; e < A1W * A1W * 8; e += NTH) {
     const int c = e & 7, p = e >> 3, y = p / A1W, x = p % A1W;
     const float *s = L.c1r + (y * C1W + x) * 8 + c;
     const float v = fmaxf(fmaxf(s[0], s[8]), fmaxf(s[C1W * 8], s[C1W * 8 + 8]));
@@ -95,61 +96,38 @@ __device__ inline void pool1(const FwdLds &L, int tid) {
   }
 }
 
-// conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  wave w owns row tiles 2w, 2w+1.
+// conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  16 output tiles (8 row x 2 column), one per wave.
 template <int SPLIT>
 __device__ inline void conv2_relu(const FwdLds &L, const float *__restrict__ b2, int tid) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
-  int base[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    int i = 16 * (2 * wave + k) + r16;
-    if (i >= C2N) i = 0;
-    base[k] = (i / C2W) * A1PW + (i % C2W);  // padded a1 pixel of tap (0,0)
-  }
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int mt = wave >> 1, j = wave & 1;
+  int i0 = 16 * mt + r16;
+  if (i0 >= C2N) i0 = 0;
+  const int base = (i0 / C2W) * A1PW + (i0 % C2W);  // padded a1 pixel of tap (0,0)
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KS2; ++s) {
     int tap = 4 * s + g;
     if (tap > 24) tap = 24;  // k-steps beyond tap 24 carry zero weights
     const int toff = (tap / 5) * A1PW + (tap % 5);
-    bf8 bh[2], bl[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int o = ((s * 32 + 16 * j + r16) * 32 + 8 * g) * 2;
-      bh[j] = *reinterpret_cast<const bf8 *>(L.w2h + o);
-      if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf8 *>(L.w2l + o);
+    const int o = ((s * 32 + 16 * j + r16) * 32 + 8 * g) * 2;
+    const bf8 bh = *reinterpret_cast<const bf8 *>(L.w2h + o);
+    const bf8 ah = *reinterpret_cast<const bf8 *>(L.a1h + (base + toff) * 16);
+    if (SPLIT == 3) {
+      const bf8 bl = *reinterpret_cast<const bf8 *>(L.w2l + o);
+      const bf8 al = *reinterpret_cast<const bf8 *>(L.a1l + (base + toff) * 16);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const bf8 ah = *reinterpret_cast<const bf8 *>(L.a1h + (base[k] + toff) * 16);
-      bf8 al;
-      if (SPLIT == 3) al = *reinterpret_cast<const bf8 *>(L.a1l + (base[k] + toff) * 16);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (SPLIT == 3) {
-          acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[k][j], 0, 0, 0);
-          acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[k][j], 0, 0, 0);
-        }
-        acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[k][j], 0, 0, 0);
-      }
-    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
   }
+  const int co = 16 * j + r16;
+  const float b = b2[co];
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int co = 16 * j + r16;
-      const float b = b2[co];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * (2 * wave + k) + 4 * g + r;
-        if (i < C2N) L.c2r[i * 32 + co] = fmaxf(acc[k][j][r] + b, 0.f);
-      }
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int i = 16 * mt + 4 * g + r;
+    if (i < C2N) L.c2r[i * 32 + co] = fmaxf(acc[r] + b, 0.f);
+  }
 }
 
 __device__ inline FwdLds carve_fwd(char *&p, int cin) {
@@ -168,21 +146,21 @@ __device__ inline FwdLds carve_fwd(char *&p, int cin) {
 
 template <int SPLIT>
 __device__ inline void stage_constants(const FwdLds &L, const FrontArgs &a, int tid) {
-  for (int e = tid; e < a.cin * XPW * XPW; e += 256) L.xs[e] = 0.f;  // zero border of the padded patch
-  for (int e = tid; e < 8 * a.cin * 25; e += 256) L.w1[e] = a.w1[e];
+  for (int e = tid; e < a.cin * XPW * XPW; e += NTH) L.xs[e] = 0.f;  // zero border of the padded patch
+  for (int e = tid; e < 8 * a.cin * 25; e += NTH) L.w1[e] = a.w1[e];
   if (tid < 8) L.w1[8 * a.cin * 25 + tid] = a.b1[tid];
-  for (int e = tid; e < A1PW * A1PW * 4; e += 256) {  // zero halo (and interior) of the a1 planes
+  for (int e = tid; e < A1PW * A1PW * 4; e += NTH) {  // zero halo (and interior) of the a1 planes
     reinterpret_cast<uint32_t *>(L.a1h)[e] = 0;
     reinterpret_cast<uint32_t *>(L.a1l)[e] = 0;
   }
-  for (int e = tid; e < KS2 * 32 * 32 / 8; e += 256) {
+  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
     reinterpret_cast<uint4 *>(L.w2h)[e] = reinterpret_cast<const uint4 *>(a.w2h)[e];
     if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[e] = reinterpret_cast<const uint4 *>(a.w2l)[e];
   }
 }
 
 template <int SPLIT>
-__global__ __launch_bounds__(256) void front_fwd_kernel(FrontArgs a) {
+__global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *p = lds;
   const FwdLds L = carve_fwd(p, a.cin);
@@ -199,7 +177,7 @@ __global__ __launch_bounds__(256) void front_fwd_kernel(FrontArgs a) {
     conv2_relu<SPLIT>(L, a.b2, tid);
     __syncthreads();
     // maxpool 2x2/1 -> output planes [100][32]
-    for (int e = tid; e < ON * 32; e += 256) {
+    for (int e = tid; e < ON * 32; e += NTH) {
       const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
       const float *s = L.c2r + (y * C2W + x) * 32 + c;
       const float v = fmaxf(fmaxf(s[0], s[32]), fmaxf(s[C2W * 32], s[C2W * 32 + 32]));
@@ -263,7 +241,7 @@ __device__ inline int argmax4(float a, float b, float c, float d) {
 }
 
 template <int SPLIT>
-__global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
+__global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *p = lds;
   const int cin = a.f.cin;
@@ -277,23 +255,22 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   stage_constants<SPLIT>(L, a.f, tid);
-  for (int e = tid; e < 25 * 8 * 32 / 8; e += 256) {
+  for (int e = tid; e < 25 * 8 * 32 / 8; e += NTH) {
     reinterpret_cast<uint4 *>(wbh)[e] = reinterpret_cast<const uint4 *>(a.w2bh)[e];
     if (SPLIT == 3) reinterpret_cast<uint4 *>(wbl)[e] = reinterpret_cast<const uint4 *>(a.w2bl)[e];
   }
-  for (int e = tid; e < D2PW * D2PW * 16; e += 256) {  // zero the padded gradient planes once (halo stays zero)
+  for (int e = tid; e < D2PW * D2PW * 16; e += NTH) {  // zero the padded gradient planes once (halo stays zero)
     reinterpret_cast<uint32_t *>(d2h)[e] = 0;
     reinterpret_cast<uint32_t *>(d2l)[e] = 0;
   }
   __syncthreads();
 
-  // conv2 weight-gradient tiles: M = 32 co (2 tiles), N = 13 tiles of (2 taps x 8 ci); wave w owns N tiles w, w+4, ...
-  f32x4 wacc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float db2 = 0.f, dw1[2] = {0.f, 0.f}, db1 = 0.f;
+  // conv2 weight-gradient tiles: M = 32 co (2 tiles) x N = 13 tiles of (2 taps x 8 ci) = 26 tiles;
+  // wave w owns tile w (and tile w + 16 for w < 10): tile t -> (co tile t & 1, N tile t >> 1)
+  f32x4 wacc[2];
+  wacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2 = 0.f, dw1 = 0.f, db1 = 0.f;
 
   const uint32_t d2h_a = (uint32_t)(uintptr_t)(lds_cp)d2h, d2l_a = (uint32_t)(uintptr_t)(lds_cp)d2l;
   const uint32_t a1h_a = (uint32_t)(uintptr_t)(lds_cp)L.a1h, a1l_a = (uint32_t)(uintptr_t)(lds_cp)L.a1l;
@@ -303,7 +280,7 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
   for (int pt = p_begin; pt < p_end; ++pt) {
     // ---- recompute the forward of this patch ---------------------------------------------------
     load_patch(a.f.x + (long)pt * cin * 256, cin, L.xs, tid);
-    for (int e = tid; e < ON * 32; e += 256) dyb[e] = a.dy[(long)pt * ON * 32 + e];
+    for (int e = tid; e < ON * 32; e += NTH) dyb[e] = a.dy[(long)pt * ON * 32 + e];
     __syncthreads();
     conv1_relu(L, cin, tid);
     __syncthreads();
@@ -313,7 +290,7 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
     __syncthreads();
 
     // ---- pool2 + ReLU2 backward: dC2[pix][co] (masked) -> padded bf16 planes, bias gradient ------
-    for (int e = tid; e < C2N * 32; e += 256) {
+    for (int e = tid; e < C2N * 32; e += NTH) {
       const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
       float gsum = 0.f;
       const float mine = L.c2r[e];
@@ -350,35 +327,31 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
         // A: dC2^T, rows = pixels (padded plane index, or halo pixel 0 for dummy rows), 16 co per tile
         const uint32_t ya_lo = (v_lo ? ((y_lo + 4) * D2PW + x_lo + 4) : 0) * 64 + 8 * (pq & 1) + 16 * (pq >> 1);
         const uint32_t ya_hi = (v_hi ? ((y_hi + 4) * D2PW + x_hi + 4) : 0) * 64 + 8 * (pq & 1) + 16 * (pq >> 1);
-        bf8 ah[2], al[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[i] = tr_pair(d2h_a + ya_lo + 32 * i, d2h_a + ya_hi + 32 * i);
-          if (SPLIT == 3) al[i] = tr_pair(d2l_a + ya_lo + 32 * i, d2l_a + ya_hi + 32 * i);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int nt = wave + 4 * j;  // N tile = taps 2 nt, 2 nt + 1
-          if (nt < 13) {                // wave-uniform
+        for (int u = 0; u < 2; ++u) {
+          const int tile = wave + NWV * u;
+          if (tile < 26) {  // wave-uniform
+            const int i = tile & 1, nt = tile >> 1;
             int tap = 2 * nt + (pq >> 1);
-            if (tap > 24) tap = 24;     // the 26th tap does not exist: recompute tap 24, dropped at the end
+            if (tap > 24) tap = 24;  // the 26th tap does not exist: recompute tap 24, dropped at the end
             const int toff = (tap / 5) * A1PW + (tap % 5);
             // B: a1 padded plane [pix][8 ci] (16 B rows): fragment columns 0-7 = tap 2nt, 8-15 = tap 2nt+1
             const uint32_t xa_lo = ((y_lo * A1PW + x_lo) + toff) * 16 + 8 * (pq & 1);
             const uint32_t xa_hi = ((y_hi * A1PW + x_hi) + toff) * 16 + 8 * (pq & 1);
+            const bf8 ah = tr_pair(d2h_a + ya_lo + 32 * i, d2h_a + ya_hi + 32 * i);
             const bf8 bh = tr_pair(a1h_a + xa_lo, a1h_a + xa_hi);
-            bf8 bl;
-            if (SPLIT == 3) bl = tr_pair(a1l_a + xa_lo, a1l_a + xa_hi);
+            bf8 al, bl;
+            if (SPLIT == 3) {
+              al = tr_pair(d2l_a + ya_lo + 32 * i, d2l_a + ya_hi + 32 * i);
+              bl = tr_pair(a1l_a + xa_lo, a1l_a + xa_hi);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              if (SPLIT == 3) {
-                wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, wacc[i][j], 0, 0, 0);
-                wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, wacc[i][j], 0, 0, 0);
-              }
-              wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, wacc[i][j], 0, 0, 0);
+            if (SPLIT == 3) {
+              wacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[u], 0, 0, 0);
+              wacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[u], 0, 0, 0);
             }
+            wacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[u], 0, 0, 0);
           }
         }
       }
@@ -386,56 +359,44 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
 
     // ---- conv2 backward-data: dA1[ya][xa][ci] = sum_{tap,co} dC2[ya - ty + 1][xa - tx + 1][co] W2[co][ci][tap] ----
     {
-      f32x4 dacc[3];
-      int base[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        dacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int i = 16 * (3 * wave + k) + r16;  // 169 pixels -> 11 row tiles (wave 3 has 2)
+      f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wave < 11) {  // 169 pixels -> 11 row tiles, one per wave (wave-uniform)
+        int i = 16 * wave + r16;
         if (i >= A1W * A1W) i = 0;
-        base[k] = ((i / A1W) + 5) * D2PW + (i % A1W) + 5;  // padded dC2 pixel of tap (0,0); tap shifts by -(ty*19 + tx)
-      }
+        const int base = ((i / A1W) + 5) * D2PW + (i % A1W) + 5;  // padded dC2 pixel of tap (0,0); tap shifts by -(ty*19 + tx)
 #pragma unroll 5
-      for (int tap = 0; tap < 25; ++tap) {
-        const int toff = (tap / 5) * D2PW + (tap % 5);
-        // B: backward weights [tap][ci][32 co]: lane (ci = r16, k = co 8g..8g+7); ci >= 8 are zero columns
-        bf8 bh, bl;
-        const s8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-        bh = __builtin_bit_cast(bf8, z);
-        bl = bh;
-        if (r16 < 8) {
-          const int o = ((tap * 8 + r16) * 32 + 8 * g) * 2;
-          bh = *reinterpret_cast<const bf8 *>(wbh + o);
-          if (SPLIT == 3) bl = *reinterpret_cast<const bf8 *>(wbl + o);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          if (3 * wave + k < 11) {  // wave-uniform
-            const int o = (base[k] - toff) * 64 + 16 * g;
-            const bf8 ah = *reinterpret_cast<const bf8 *>(d2h + o);
-            if (SPLIT == 3) {
-              const bf8 al = *reinterpret_cast<const bf8 *>(d2l + o);
-              dacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, dacc[k], 0, 0, 0);
-              dacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, dacc[k], 0, 0, 0);
-            }
-            dacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, dacc[k], 0, 0, 0);
+        for (int tap = 0; tap < 25; ++tap) {
+          const int toff = (tap / 5) * D2PW + (tap % 5);
+          // B: backward weights [tap][ci][32 co]: lane (ci = r16, k = co 8g..8g+7); ci >= 8 are zero columns
+          const s8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+          bf8 bh = __builtin_bit_cast(bf8, z), bl = bh;
+          if (r16 < 8) {
+            const int o = ((tap * 8 + r16) * 32 + 8 * g) * 2;
+            bh = *reinterpret_cast<const bf8 *>(wbh + o);
+            if (SPLIT == 3) bl = *reinterpret_cast<const bf8 *>(wbl + o);
           }
+          const int o = (base - toff) * 64 + 16 * g;
+          const bf8 ah = *reinterpret_cast<const bf8 *>(d2h + o);
+          if (SPLIT == 3) {
+            const bf8 al = *reinterpret_cast<const bf8 *>(d2l + o);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, dacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, dacc, 0, 0, 0);
+          }
+          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, dacc, 0, 0, 0);
         }
       }
-      __syncthreads();  // dyb (aliased by dA1) and the d2 planes are no longer read by the weight-gradient phase
+      __syncthreads();  // dyb (aliased by dA1) is no longer read
+      if (wave < 11 && r16 < 8)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (r16 < 8)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * (3 * wave + k) + 4 * g + r;
-            if (3 * wave + k < 11 && i < A1W * A1W) dA1[i * 8 + r16] = dacc[k][r];
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * wave + 4 * g + r;
+          if (i < A1W * A1W) dA1[i * 8 + r16] = dacc[r];
+        }
     }
     __syncthreads();
 
     // ---- pool1 + ReLU1 backward -> dC1 [196][8]; then the d2 planes' interior is cleared for the next patch ----
-    for (int e = tid; e < C1N * 8; e += 256) {
+    for (int e = tid; e < C1N * 8; e += NTH) {
       const int co = e & 7, pix = e >> 3, y = pix / C1W, x = pix % C1W;
       float gsum = 0.f;
       if (L.c1r[e] > 0.f) {
@@ -454,20 +415,15 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
     }
     __syncthreads();
 
-    // ---- conv1 weight / bias gradient (VALU): element t = tid (+256) < 8*cin*25 is dW1[co][ci][tap] ----
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int t = tid + 256 * h;
-      if (t < 8 * cin * 25) {
-        const int tap = t % 25, ci = (t / 25) % cin, co = t / (25 * cin);
-        const float *xs = L.xs + (ci * XPW + tap / 5) * XPW + tap % 5;
-        float s = 0.f;
-        for (int pix = 0; pix < C1N; ++pix) s = fmaf(dC1[pix * 8 + co], xs[(pix / C1W) * XPW + pix % C1W], s);
-        dw1[h] += s;
-      }
-    }
-    if (tid >= 248) {  // the last 8 threads also own the bias gradient of conv1
-      const int co = tid - 248;
+    // ---- conv1 weight / bias gradient (VALU): thread t < 8*cin*25 owns dW1[co][ci][tap]; threads 1016.. own db1 ----
+    if (tid < 8 * cin * 25) {
+      const int tap = tid % 25, ci = (tid / 25) % cin, co = tid / (25 * cin);
+      const float *xs = L.xs + (ci * XPW + tap / 5) * XPW + tap % 5;
+      float s = 0.f;
+      for (int pix = 0; pix < C1N; ++pix) s = fmaf(dC1[pix * 8 + co], xs[(pix / C1W) * XPW + pix % C1W], s);
+      dw1 += s;
+    } else if (tid >= NTH - 8) {
+      const int co = tid - (NTH - 8);
       float s = 0.f;
       for (int pix = 0; pix < C1N; ++pix) s += dC1[pix * 8 + co];
       db1 += s;
@@ -478,29 +434,27 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(FrontBwdArgs a) {
   // ---- partial sums of this slice -> workspace ------------------------------------------------------
   const int PART = 32 * 8 * 25 + 32 + 8 * cin * 25 + 8;
   float *out = a.part + (long)blockIdx.x * PART;
-  // wacc[i][j][r] = dW2[co = 16 i + 4 g + r][ci = r16 & 7][tap = 2 (wave + 4 j) + (r16 >> 3)]
+  // wacc[u][r] of tile t = wave + 16 u: dW2[co = 16 (t & 1) + 4 g + r][ci = r16 & 7][tap = 2 (t >> 1) + (r16 >> 3)]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int u = 0; u < 2; ++u) {
+    const int tile = wave + NWV * u;
+    const int tap = 2 * (tile >> 1) + (r16 >> 3);
+    if (tile < 26 && tap < 25)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int tap = 2 * (wave + 4 * j) + (r16 >> 3);
-      if (wave + 4 * j < 13 && tap < 25)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[((16 * i + 4 * g + r) * 8 + (r16 & 7)) * 25 + tap] = wacc[i][j][r];
-    }
-  // db2: thread t summed channel t & 31 over its pixel subset -> reduce the 8 threads per channel through LDS
+      for (int r = 0; r < 4; ++r) out[((16 * (tile & 1) + 4 * g + r) * 8 + (r16 & 7)) * 25 + tap] = wacc[u][r];
+  }
+  // db2: thread t summed channel t & 31 over its pixel subset -> reduce the 32 threads per channel through LDS
   __syncthreads();
   float *red = reinterpret_cast<float *>(lds);
   red[tid] = db2;
   __syncthreads();
   if (tid < 32) {
     float s = 0.f;
-    for (int k = 0; k < 8; ++k) s += red[tid + 32 * k];
+    for (int k = 0; k < NTH / 32; ++k) s += red[tid + 32 * k];
     out[32 * 8 * 25 + tid] = s;
   }
-  if (tid < 8 * cin * 25) out[32 * 8 * 25 + 32 + tid] = dw1[0];
-  if (tid + 256 < 8 * cin * 25) out[32 * 8 * 25 + 32 + tid + 256] = dw1[1];
-  if (tid >= 248) out[32 * 8 * 25 + 32 + 8 * cin * 25 + (tid - 248)] = db1;
+  if (tid < 8 * cin * 25) out[32 * 8 * 25 + 32 + tid] = dw1;
+  if (tid >= NTH - 8) out[32 * 8 * 25 + 32 + 8 * cin * 25 + (tid - (NTH - 8))] = db1;
 }
 
 // out[e] = sum_k part[k * stride + e], e < n   (fixed order -> deterministic)
@@ -549,9 +503,9 @@ int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1
   if (split == 3 && (!w2_lo || !y_lo)) return CRW_EINVAL;
   FrontArgs a{x, w1, b1, w2_hi, w2_lo, b2, y_hi, y_lo, P, cin};
   const size_t lds = fwd_lds_bytes(cin);
-  const int grid = P < 1024 ? P : 1024;
-  if (split == 3) hipLaunchKernelGGL(front_fwd_kernel<3>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(front_fwd_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  const int grid = P < 512 ? P : 512;  // two 1024-thread workgroups (60 KB of LDS each) per CU
+  if (split == 3) hipLaunchKernelGGL(front_fwd_kernel<3>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(front_fwd_kernel<1>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
   return check_launch();
 }
 
@@ -582,14 +536,14 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
           hipSuccess) return CRW_EHIP;
       attr3 = true;
     }
-    hipLaunchKernelGGL(front_bwd_kernel<3>, dim3(nslice), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(front_bwd_kernel<3>, dim3(nslice), dim3(NTH), lds, s, a);
   } else {
     if (!attr1) {
       if (hipFuncSetAttribute((const void *)front_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
           hipSuccess) return CRW_EHIP;
       attr1 = true;
     }
-    hipLaunchKernelGGL(front_bwd_kernel<1>, dim3(nslice), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(front_bwd_kernel<1>, dim3(nslice), dim3(NTH), lds, s, a);
   }
   CRW_TRY(check_launch());
   const int n2 = 32 * 8 * 25, n1 = 8 * cin * 25, PART = n2 + 32 + n1 + 8;
