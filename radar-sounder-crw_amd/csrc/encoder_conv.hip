@@ -555,6 +555,17 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float *__restrict_
   }
 }
 
+// few outputs, many slices (bias gradients): one wave per output, lanes stride the slices, fixed shuffle tree
+__global__ __launch_bounds__(256) void slice_sum_wave_kernel(const float *__restrict__ part, int nslice, long stride,
+                                                             int n, float *__restrict__ out) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < nslice; k += 64) s += part[(long)k * stride + e];
+  s = wave_sum(s);
+  if (lane == 0) out[e] = s;
+}
+
 // same for the weight gradient: slabs are [tap][co*ci], the result is the framework layout [co*ci][tap]
 __global__ __launch_bounds__(256) void slice_sum_dw_kernel(const float *__restrict__ part, int nslice, int coci,
                                                            float *__restrict__ out) {
@@ -756,7 +767,8 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
   hipLaunchKernelGGL(slice_sum_dw_kernel, dim3(ew_grid(nw)), dim3(256), 0, s, dw_part, nslice, cout * cin, dw);
-  hipLaunchKernelGGL(slice_sum_kernel, dim3(1), dim3(256), 0, s, db_part, nslice * wgrad_groups(cin), (long)cout, db);
+  hipLaunchKernelGGL(slice_sum_wave_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, db_part, nslice * wgrad_groups(cin),
+                     (long)cout, cout, db);
   return check_launch();
 }
 

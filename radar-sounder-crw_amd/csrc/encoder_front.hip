@@ -457,14 +457,16 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   if (tid >= NTH - 8) out[32 * 8 * 25 + 32 + 8 * cin * 25 + (tid - (NTH - 8))] = db1;
 }
 
-// out[e] = sum_k part[k * stride + e], e < n   (fixed order -> deterministic)
+// out[e] = sum_k part[k * stride + e], e < n: one wave per output, lanes stride the slices, fixed
+// shuffle tree (deterministic)
 __global__ __launch_bounds__(256) void front_slice_sum_kernel(const float *__restrict__ part, int nslice, int stride,
                                                               int n, float *__restrict__ out) {
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < nslice; ++k) s += part[(long)k * stride + e];
-    out[e] = s;
-  }
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < nslice; k += 64) s += part[(long)k * stride + e];
+  s = wave_sum(s);
+  if (lane == 0) out[e] = s;
 }
 
 size_t fwd_lds_bytes(int cin) {
@@ -551,7 +553,7 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
   float *part = (float *)ws;
   struct Seg { int off, n; float *dst; } segs[4] = {{0, n2, dw2}, {n2, 32, db2}, {n2 + 32, n1, dw1}, {n2 + 32 + n1, 8, db1}};
   for (auto &sg : segs)
-    hipLaunchKernelGGL(front_slice_sum_kernel, dim3((sg.n + 255) / 256), dim3(256), 0, s, part + sg.off, nslice, PART,
+    hipLaunchKernelGGL(front_slice_sum_kernel, dim3((sg.n + 3) / 4), dim3(256), 0, s, part + sg.off, nslice, PART,
                        sg.n, sg.dst);
   return check_launch();
 }
