@@ -118,7 +118,8 @@ def test_no_cycle_T2(hip):
 
 
 @pytest.mark.parametrize("B,T,N,C,tau", [(2, 5, 100, 64, 0.05), (1, 4, 130, 32, 0.1), (1, 3, 200, 128, 0.02),
-                                         (3, 6, 33, 20, 0.07), (1, 5, 257, 16, 0.2)])
+                                         (3, 6, 33, 20, 0.07), (1, 5, 257, 16, 0.2), (1, 4, 1100, 16, 0.3),
+                                         (5, 9, 32, 8, 0.1), (2, 4, 64, 12, 0.05)])
 def test_training_path_matches_oracle_seeded(hip, B, T, N, C, tau):
     import model as crw_model
     g = torch.Generator().manual_seed(B * 1000 + N)
@@ -316,6 +317,26 @@ def test_predict_frame_by_frame_equals_batched(hip):
         ml.append(m)
     assert np.array_equal(pred_all.cpu().numpy(), g["pred"])
     assert lp.mask.shape == (1, N, N) and lp.mask_hw == (N, 1)
+
+
+@pytest.mark.parametrize("T,N,C,M,cxt,radius,knn,temp", [(10, 12, 16, 3, 3, 2, 5, 0.1),    # knn > in-band keys of the first frames
+                                                         (9, 7, 10, 2, 2, 1, 3, 0.05),    # radius 1: only the same node is in band
+                                                         (30, 20, 24, 4, 5, 30, 20, 0.2),  # radius > N: no mask at all, knn = N
+                                                         (6, 5, 7, 3, 100, 2, 2, 0.1)])   # C not a multiple of 4 (scalar dot path)
+def test_labelprop_edge_cases_match_oracle(hip, T, N, C, M, cxt, radius, knn, temp):
+    from imported.labelprop import LabelPropVOS_CRW
+    g = torch.Generator().manual_seed(T * 100 + N)
+    proto = torch.randn(N + 8, C, generator=g)
+    t = torch.arange(T).float()
+    depth = torch.arange(N).float()[None] + 1.5 * torch.sin(2 * np.pi * t / 7)[:, None] + 3
+    lo = depth.floor().long()
+    fr = (depth - lo.float()).unsqueeze(-1)
+    emb = (proto[lo] * (1 - fr) + proto[lo + 1] * fr + 0.3 * torch.randn(T, N, C, generator=g)).float()
+    seed = (torch.arange(N) * M // N).float()
+    ref = orc.labelprop(emb.numpy(), seed.numpy(), M, cxt, radius, temp, knn)
+    feats = hip.normalize(emb.cuda())
+    pred, _ = LabelPropVOS_CRW(dict(CXT_SIZE=cxt, RADIUS=radius, TEMP=temp, KNN=knn)).propagate_all(feats, seed.cuda(), M)
+    assert np.array_equal(pred.cpu().numpy(), ref), f"{(pred.cpu().numpy() != ref).sum()} of {ref.size} labels differ"
 
 
 def test_labelprop_matches_oracle_mcords_shape(hip):
