@@ -115,8 +115,9 @@ int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int
 /* encoder: hand-written 3x3 convolutions of CNN (conv3/conv4/conv5, src/encoder.py:26-35) --------- */
 /* Activations are channels-last bf16 planes [P][100][C] ("hi" plane and, for split = 3, a "lo"
  * plane: x = hi + lo to ~1e-5 relative).  10x10 feature maps (16x16 input patches).
- * fp32 conv weight [cout][cin][3][3] -> forward planes [9][cout][cin] and backward-data planes
- * (taps flipped, [9][cin][cout]); lo planes may be NULL together (plain bf16). */
+ * fp32 conv weight [cout][cin][3][3] -> forward planes and backward-data planes (taps flipped, cin <-> cout),
+ * 9*cout*cin bf16 each, stored in MFMA fragment order (opaque to the caller); lo planes may be NULL
+ * together (plain bf16). */
 int crw_enc_pack_weights(const float *w, int cout, int cin, uint16_t *fwd_hi, uint16_t *fwd_lo,
                          uint16_t *bwd_hi, uint16_t *bwd_lo, crw_stream_t stream);
 /* fp32 NCHW [P][C][10][10] (output of pool2) -> planes */

@@ -131,7 +131,7 @@ __device__ inline void zero_halo(char *plane, int tid) {
 
 struct ConvArgs {
   const uint16_t *xh, *xl;   // [P][100][CIN] input planes
-  const uint16_t *wh, *wl;   // [9][COUT][CIN] weights (already flipped/transposed for backward-data)
+  const uint16_t *wh, *wl;   // weights in fragment order (pack_weights_kernel; flipped/transposed for backward-data)
   const float *bias;         // [COUT] (MODE 0) or null
   const uint16_t *maskh;     // [P][100][COUT]: output is zeroed where this plane is 0 (MODE 1) or null
   uint16_t *yh, *yl;         // [P][100][COUT] output planes or null
@@ -140,6 +140,7 @@ struct ConvArgs {
   const float *dgap;         // MODE 1, optional [P][CIN]: the input gradient is dgap/100 gated by xh (= forward
                              // activation hi plane) instead of being read from xh/xl
   int P;
+  long long *stamps;         // diagnostic builds only: [grid][5] s_memtime at phase boundaries (else null)
 };
 
 // PPW patches per workgroup, processed by the SAME four waves: every weight fragment a wave pulls
@@ -162,6 +163,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
 
+  auto stamp = [&](int k) {  // phase timestamps, only in `make STAMPS=1` builds (tools/stamp_probe.py)
+#ifdef CRW_CONV_STAMPS
+    if (a.stamps && tid == 0) a.stamps[(long)blockIdx.x * 5 + k] = (long long)__builtin_amdgcn_s_memtime();
+#else
+    (void)k;
+#endif
+  };
+  stamp(0);
   // ---- patches -> LDS ----------------------------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
+  stamp(1);
 
   // row tile mt, row r16 -> interior pixel i -> padded index of the tap-(0,0) source pixel
   const int wm = wave / WN, wn = wave % WN;
@@ -204,14 +214,16 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     const int tap = step / KCH, cc = step % KCH;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      const long o = ((long)tap * COUT + co_w + 16 * j + r16) * CIN + 32 * cc + 8 * g;
+      // weights are packed in fragment order: one wave-instruction reads 1 KiB contiguous (8 full
+      // cache lines) instead of 16 half lines of a [co][ci] row layout
+      const long o = ((((long)tap * KCH + cc) * (COUT / 16) + (co_w / 16 + j)) * 64 + lane) * 8;
       bh[j] = *reinterpret_cast<const bf8 *>(a.wh + o);
       if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf8 *>(a.wl + o);
     }
   };
 
   constexpr int NSTEP = 9 * KCH;
-  constexpr int AHEAD = 3;  // weight fragments are requested 3 k-steps before use: L2 latency under load
+  constexpr int AHEAD = 4;  // weight fragments are requested 4 k-steps before use
   auto do_step = [&](int step, bf8 (&bhc)[NTW], bf8 (&blc)[NTW], bf8 (&bhn)[NTW], bf8 (&bln)[NTW]) {
     if (step + AHEAD < NSTEP) load_b(step + AHEAD, bhn, bln);
     const int tap = step / KCH, cc = step % KCH;
@@ -237,29 +249,38 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         }
       }
   };
-  // four register sets for the weight fragments, rotated with static indices (a run-time index
-  // would send them to scratch): step s uses set s % 4 and refills set (s + 3) % 4
-  bf8 bh0[NTW], bl0[NTW], bh1[NTW], bl1[NTW], bh2[NTW], bl2[NTW], bh3[NTW], bl3[NTW];
+  // five register sets for the weight fragments, rotated with static indices (a run-time index would
+  // send them to scratch): step s uses set s % 5 and refills set (s + 4) % 5, i.e. 4 k-steps of
+  // weight loads (16 KiB per wave in bf16x3) are in flight -- the kernel is bound by how many bytes
+  // per clock the CU can pull from L2, which scales with the requests kept outstanding.  Six sets
+  // measured faster per workgroup but push conv5 past 256 registers (one workgroup per CU: slower).
+  bf8 bh0[NTW], bl0[NTW], bh1[NTW], bl1[NTW], bh2[NTW], bl2[NTW], bh3[NTW], bl3[NTW], bh4[NTW], bl4[NTW];
   load_b(0, bh0, bl0);
-  if (NSTEP > 1) load_b(1, bh1, bl1);
-  if (NSTEP > 2) load_b(2, bh2, bl2);
+  load_b(1, bh1, bl1);
+  load_b(2, bh2, bl2);
+  load_b(3, bh3, bl3);
+  static_assert(NSTEP >= 9, "NSTEP");
   int step = 0;
-  for (; step + 4 <= NSTEP; step += 4) {
-    do_step(step, bh0, bl0, bh3, bl3);
+  for (; step + 5 <= NSTEP; step += 5) {
+    do_step(step, bh0, bl0, bh4, bl4);
     do_step(step + 1, bh1, bl1, bh0, bl0);
     do_step(step + 2, bh2, bl2, bh1, bl1);
     do_step(step + 3, bh3, bl3, bh2, bl2);
+    do_step(step + 4, bh4, bl4, bh3, bl3);
   }
-  if (NSTEP % 4 >= 1) do_step(step, bh0, bl0, bh3, bl3);
-  if (NSTEP % 4 >= 2) do_step(step + 1, bh1, bl1, bh0, bl0);
-  if (NSTEP % 4 >= 3) do_step(step + 2, bh2, bl2, bh1, bl1);
+  if (NSTEP % 5 >= 1) do_step(step, bh0, bl0, bh4, bl4);
+  if (NSTEP % 5 >= 2) do_step(step + 1, bh1, bl1, bh0, bl0);
+  if (NSTEP % 5 >= 3) do_step(step + 2, bh2, bl2, bh1, bl1);
+  if (NSTEP % 5 >= 4) do_step(step + 3, bh3, bl3, bh2, bl2);
 
   // ---- epilogue ----------------------------------------------------------------------------------
   // C/D map: acc[q][k][j][r] = out[patch p0+q][pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
   float bias_r[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) bias_r[j] = (MODE == 0 && a.bias) ? a.bias[co_w + 16 * j + r16] : 0.f;
+  stamp(2);
   __syncthreads();  // every wave is done reading the input images: reuse LDS as the output staging
+  stamp(3);
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int p = p0 + q;
@@ -346,6 +367,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       }
     }
   }
+  stamp(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -579,7 +601,11 @@ __global__ __launch_bounds__(256) void slice_sum_dw_kernel(const float *__restri
 }
 
 // ---- small helpers --------------------------------------------------------------------------------
-// fp32 W[co][ci][3][3] -> forward planes [tap][co][ci] and backward-data planes [8-tap][ci][co]
+// fp32 W[co][ci][3][3] -> forward and backward-data (taps flipped, ci <-> co) planes, both in MFMA
+// fragment order: [tap][k-chunk of 32][16-channel output tile][lane = 16 (k/8) + channel][8 k]
+__device__ inline long frag_index(int tap, int n, int k, int N, int K) {  // n: output channel, k: reduction channel
+  return ((((long)tap * (K / 32) + k / 32) * (N / 16) + n / 16) * 64 + ((k % 32) / 8) * 16 + n % 16) * 8 + k % 8;
+}
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int CO, int CI,
                                                            uint16_t *fh, uint16_t *fl, uint16_t *bh, uint16_t *bl) {
   const long n = (long)CO * CI * 9;
@@ -587,7 +613,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
     const int tap = e % 9, ci = (e / 9) % CI, co = e / (9L * CI);
     const float v = w[e];
     const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
-    const long of = ((long)tap * CO + co) * CI + ci, ob = ((long)(8 - tap) * CI + ci) * CO + co;
+    const long of = frag_index(tap, co, ci, CO, CI), ob = frag_index(8 - tap, ci, co, CI, CO);
     fh[of] = h; bh[ob] = h;
     if (fl) { fl[of] = l; bl[ob] = l; }
   }
@@ -678,7 +704,14 @@ inline int ew_grid(long n) {
 
 using namespace crw;
 
+long long *g_conv_stamps = nullptr;  // set by crw_debug_conv_stamps (diagnostics)
+
 extern "C" {
+
+// diagnostics: when non-null, crw_enc_conv3x3 launches record s_memtime at 5 phase boundaries per workgroup
+#ifdef CRW_CONV_STAMPS
+void crw_debug_conv_stamps(long long *buf) { g_conv_stamps = buf; }
+#endif
 
 int crw_enc_pack_weights(const float *w, int cout, int cin, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi,
                          uint16_t *bwd_lo, crw_stream_t stream) {
@@ -714,7 +747,7 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
   if (split == 3 && (!w_lo || (!x_lo && !dgap))) return CRW_EINVAL;
   if (dgap && mode != 1) return CRW_EINVAL;
   if (!y_hi && !y_f32 && !gap) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, g_conv_stamps};
   hipStream_t s = (hipStream_t)stream;
 #define CRW_CONV_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
