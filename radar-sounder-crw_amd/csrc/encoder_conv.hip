@@ -22,8 +22,8 @@
 //
 // conv3x3_wgrad_kernel: dW[co,ci,tap] = sum_{p,pix} dY[p,pix,co] * X[p,pix+tap,ci]: both operands
 // are pixel-major in memory, i.e. strided along the reduction dimension, so fragments come from
-// LDS through the hardware-transposing ds_read_b64_tr_b16.  One workgroup owns all 9 taps x all
-// output channels x a group of 64 input channels, walks a slice of the patches accumulating in
+// LDS through the hardware-transposing ds_read_b64_tr_b16.  One workgroup owns all 9 taps x 64
+// output channels x a group of (up to) 64 input channels, walks a slice of the patches accumulating in
 // registers, and writes its partial sums to a workspace; a second kernel adds the slices in a
 // fixed order (bitwise reproducible, no float atomics).
 #include "crw_common.h"
@@ -62,11 +62,13 @@ template <int C, int NTHREADS>
 struct PlaneLoad {
   static constexpr int NCH = C / 8, TOTAL = NPIX * NCH, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
   uint4 v[ITER];
+  // Loads are unconditional with a clamped index (a predicated load makes the compiler branch around it,
+  // wait for it at once and park the array in scratch memory); only the LDS stores are predicated.
   __device__ inline void load(const uint16_t *__restrict__ src, int tid) {  // src: [100][C] of one patch
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-      const int c = tid + i * NTHREADS;
-      if (TOTAL % NTHREADS == 0 || c < TOTAL) v[i] = *reinterpret_cast<const uint4 *>(src + (long)c * 8);
+      const int c = min(tid + i * NTHREADS, TOTAL - 1);
+      v[i] = *reinterpret_cast<const uint4 *>(src + (long)c * 8);
     }
   }
   __device__ inline void store(char *dst, int tid) const {  // into the interior of the padded LDS image
@@ -89,8 +91,8 @@ __device__ inline void gap_planes_to_lds(const uint16_t *__restrict__ yh, const 
   uint4 v[ITER];
 #pragma unroll
   for (int i = 0; i < ITER; ++i) {
-    const int c = tid + i * NTHREADS;
-    if (TOTAL % NTHREADS == 0 || c < TOTAL) v[i] = *reinterpret_cast<const uint4 *>(yh + (long)c * 8);
+    const int c = min(tid + i * NTHREADS, TOTAL - 1);  // clamped, unconditional (see PlaneLoad)
+    v[i] = *reinterpret_cast<const uint4 *>(yh + (long)c * 8);
   }
 #pragma unroll
   for (int i = 0; i < ITER; ++i) {
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       if (mk) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-          const int c = tid + it * 256;
-          if (c < TOTAL) mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
+          const int c = min(tid + it * 256, TOTAL - 1);
+          mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
         }
       }
       for (int pl = 0; pl < NPL; ++pl) {
@@ -371,8 +373,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient.  grid = (3 tap rows, NG patch slices); 512 threads = 8 waves, wave w owns output
-// channels [w*COUT/8, +COUT/8) x all CIN x the 3 taps of its row.
+// weight gradient.  grid = (ci groups x co groups, patch slices); 256 threads = 4 waves (see the kernel).
 struct WgradArgs {
   const uint16_t *dyh, *dyl;  // [P][100][COUT] masked output gradient planes
   const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
@@ -400,170 +401,222 @@ __device__ inline bf8 tr_frag(uint32_t a_lo, uint32_t a_hi) {
   return __builtin_bit_cast(bf8, v);
 }
 
-// NCI = input channels per workgroup (blockIdx.x selects the group): the workgroup holds all 9 taps
-// x all COUT x NCI input channels in its accumulators, so a patch is fetched by CIN/NCI workgroups
-// (2 for conv5) instead of once per tap row, and only the NCI-channel slice of the X planes is loaded.
+template <int N, class F>
+__device__ inline void static_for(F &&f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// One workgroup (4 waves) = all 9 taps x WG_NCO output channels x NCI input channels of one patch
+// slice; blockIdx.x selects the (ci group, co group), blockIdx.y the slice.
+//   * A wave owns NCOW co tiles x ONE ci tile x 9 taps (36 accumulator tiles for conv4/conv5).  The dY
+//     fragments do not depend on the tap, the X fragments do, so this split needs 2 NCOW + 18 fragment
+//     reads per k-step and wave (26 for bf16x3) where one co tile x four ci tiles needs 74: the kernel
+//     is bound by LDS reads, not by the matrix cores.
+//   * X fragments are double-buffered in registers across taps (reads of tap t+1 fly during the
+//     MFMAs of tap t; counted s_waitcnt since the transposing reads are inline asm).
+//   * dY lives in LDS without a halo (only X is shifted by the tap): 100 pixel rows + one zero row for
+//     the k padding, which keeps a workgroup at 69 KiB -> two independent workgroups per CU, one
+//     loading its next patch while the other computes.
+constexpr int WG_NCO = 64, YROWS = NPIX + 1;
+
 template <int SPLIT, int CIN, int COUT, int NCI>
-__global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int NCO = WG_NCO;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
-  constexpr int XPL = plane_bytes<NCI>(), YPL = plane_bytes<COUT>();  // bytes per LDS plane
-  static_assert(COUT == 128 || COUT == 64, "COUT");
-  constexpr int NT = NCI / 16;  // ci tiles of this group
+  constexpr int XPL = plane_bytes<NCI>();                  // X plane: 12x12 padded image, NCI channels
+  constexpr int YS = row_stride<NCO>(), YPL = YROWS * YS;  // dY plane: compact rows
+  constexpr int NT = NCI / 16;                              // ci tiles of this group
+  constexpr int WCI = NT < 4 ? NT : 4, WCO = 4 / WCI;      // waves along ci tiles / co tiles
+  constexpr int NCOW = NCO / 16 / WCO;                     // co tiles per wave
+  static_assert(NT == WCI && COUT % NCO == 0 && CIN % NCI == 0, "tiling");
+  constexpr int NGRP_CI = CIN / NCI;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *xs = lds, *ys = lds + NPL * XPL;
 
-  const int grp = blockIdx.x, ci_base = grp * NCI;
-  constexpr int NGRP = CIN / NCI;
+  const int grp_ci = blockIdx.x % NGRP_CI, grp_co = blockIdx.x / NGRP_CI;
+  const int ci_base = grp_ci * NCI, co_base = grp_co * NCO;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  // COUT = 128: wave w owns output channels [16 w, 16 w + 16) and all NT ci tiles.
-  // COUT = 64 : only 4 co tiles exist; waves 4..7 repeat them on the other half of the ci tiles.
-  constexpr bool SPLIT_N = (COUT == 64);
-  const int co0 = SPLIT_N ? (wave & 3) * 16 : wave * 16;
-  constexpr int NTW = SPLIT_N ? NT / 2 : NT;  // ci tiles per wave
-  static_assert(NTW >= 1, "tiles");
-  const int nt0 = SPLIT_N ? (wave >> 2) * NTW : 0;
+  const int wci = wave % WCI, wco = wave / WCI;
+  const int co0w = wco * NCOW * 16;  // first output channel of this wave inside the workgroup's NCO
 
-  f32x4 acc[9][NTW];
+  f32x4 acc[9][NCOW];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NCOW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbsum = 0.f;
 
   const int p_begin = blockIdx.y * a.patches_per_block;
   const int p_end = min(a.P, p_begin + a.patches_per_block);
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
 
-  // the halo of the LDS images is zeroed once; patch loads only ever touch the interior
-  zero_halo<NCI, 512>(xs, tid);
-  zero_halo<COUT, 512>(ys, tid);
-  if (SPLIT == 3) {
-    zero_halo<NCI, 512>(xs + XPL, tid);
-    zero_halo<COUT, 512>(ys + YPL, tid);
-  }
-  constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + 511) / 512;
+  // zeroed once: the halo of the X images and the k-padding row of the dY planes
+  zero_halo<NCI, 256>(xs, tid);
+  if (SPLIT == 3) zero_halo<NCI, 256>(xs + XPL, tid);
+  if (tid < NPL * (YS / 16)) *reinterpret_cast<uint4 *>(ys + (tid / (YS / 16)) * YPL + NPIX * YS + 16 * (tid % (YS / 16))) = uint4{0, 0, 0, 0};
+
+  constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + 255) / 256;
+  constexpr int YCH = NCO / 8, YTOT = NPIX * YCH, YIT = (YTOT + 255) / 256;
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();  // previous patch fully consumed
     {
-      // X: the NCI-channel slice [ci_base, ci_base + NCI) of every interior pixel (hi, then lo)
-      uint4 xv[XIT];
+      // all global loads of the patch are issued before the first LDS store (one round trip)
+      uint4 xv[NPL][XIT], yv[NPL][YIT];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
         const uint16_t *src = (pl ? a.xl : a.xh) + (long)p * NPIX * CIN + ci_base;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-          const int c = tid + i * 512;
-          if (XTOT % 512 == 0 || c < XTOT) xv[i] = *reinterpret_cast<const uint4 *>(src + (long)(c / XCH) * CIN + 8 * (c % XCH));
-        }
-#pragma unroll
-        for (int i = 0; i < XIT; ++i) {
-          const int c = tid + i * 512;
-          if (XTOT % 512 == 0 || c < XTOT)
-            *reinterpret_cast<uint4 *>(xs + pl * XPL + px_off<NCI>(interior_pp(c / XCH), c % XCH)) = xv[i];
+          const int c = min(tid + i * 256, XTOT - 1);  // clamped, unconditional (see PlaneLoad)
+          xv[pl][i] = *reinterpret_cast<const uint4 *>(src + (long)(c / XCH) * CIN + 8 * (c % XCH));
         }
       }
-      if (a.dgap) {
-        gap_planes_to_lds<COUT, 512, SPLIT>(a.dyh + (long)p * NPIX * COUT, a.dgap + (long)p * COUT, ys, ys + YPL, tid);
-      } else {
-        PlaneLoad<COUT, 512> yh_, yl_;
-        yh_.load(a.dyh + (long)p * NPIX * COUT, tid);
-        yh_.store(ys, tid);
-        if (SPLIT == 3) {
-          yl_.load(a.dyl + (long)p * NPIX * COUT, tid);
-          yl_.store(ys + YPL, tid);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        // (the fused ReLU + GAP backward builds both planes from the activation hi plane: dyl is null then)
+        const uint16_t *src = ((pl && !a.dgap) ? a.dyl : a.dyh) + (long)p * NPIX * COUT + co_base;
+#pragma unroll
+        for (int i = 0; i < YIT; ++i) {
+          const int c = min(tid + i * 256, YTOT - 1);
+          yv[pl][i] = *reinterpret_cast<const uint4 *>(src + (long)(c / YCH) * COUT + 8 * (c % YCH));
         }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+          const int c = tid + i * 256;
+          if (XTOT % 256 == 0 || c < XTOT)
+            *reinterpret_cast<uint4 *>(xs + pl * XPL + px_off<NCI>(interior_pp(c / XCH), c % XCH)) = xv[pl][i];
+        }
+      if (a.dgap) {
+        // dY[i][c] = dgap[c] / 100 where the forward activation (hi plane, in yv[0]) is non-zero
+        const float *dg = a.dgap + (long)p * COUT + co_base;
+#pragma unroll
+        for (int i = 0; i < YIT; ++i) {
+          const int c = tid + i * 256;
+          if (YTOT % 256 == 0 || c < YTOT) {
+            const int ch = c % YCH;
+            const float4 g0 = *reinterpret_cast<const float4 *>(dg + 8 * ch);
+            const float4 g1 = *reinterpret_cast<const float4 *>(dg + 8 * ch + 4);
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const uint32_t yw[4] = {yv[0][i].x, yv[0][i].y, yv[0][i].z, yv[0][i].w};
+            uint32_t oh[4], ol[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float a0 = (yw[w] & 0x7fffu) ? gv[2 * w] * (1.0f / NPIX) : 0.f;
+              const float a1 = (yw[w] & 0x7fff0000u) ? gv[2 * w + 1] * (1.0f / NPIX) : 0.f;
+              const uint16_t h0 = f2bf(a0), h1 = f2bf(a1);
+              oh[w] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+              ol[w] = (uint32_t)f2bf(a0 - bf2f(h0)) | ((uint32_t)f2bf(a1 - bf2f(h1)) << 16);
+            }
+            const int off = (c / YCH) * YS + 16 * ch;
+            *reinterpret_cast<uint4 *>(ys + off) = uint4{oh[0], oh[1], oh[2], oh[3]};
+            if (SPLIT == 3) *reinterpret_cast<uint4 *>(ys + YPL + off) = uint4{ol[0], ol[1], ol[2], ol[3]};
+          }
+        }
+      } else {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int i = 0; i < YIT; ++i) {
+            const int c = tid + i * 256;
+            if (YTOT % 256 == 0 || c < YTOT) *reinterpret_cast<uint4 *>(ys + pl * YPL + (c / YCH) * YS + 16 * (c % YCH)) = yv[pl][i];
+          }
       }
     }
     __syncthreads();
-    // bias gradient: thread -> channel tid % COUT, pixels part, part + PARTS*NGRP, ... of this group's share
+    // bias gradient: thread -> channel tid % NCO of this co group; the ci groups share out the pixels
     {
-      constexpr int PARTS = 512 / COUT;
-      const int c = tid % COUT, part = tid / COUT;
+      constexpr int PARTS = 256 / NCO;
+      const int c = tid % NCO, part = tid / NCO;
       float s = 0.f;
-      for (int i = part * NGRP + grp; i < NPIX; i += PARTS * NGRP) {
-        const int o = px_off<COUT>(interior_pp(i), c >> 3) + 2 * (c & 7);
+      for (int i = part * NGRP_CI + grp_ci; i < NPIX; i += PARTS * NGRP_CI) {
+        const int o = i * YS + 2 * c;
         s += bf2f(*reinterpret_cast<const uint16_t *>(ys + o));
         if (SPLIT == 3) s += bf2f(*reinterpret_cast<const uint16_t *>(ys + YPL + o));
       }
       dbsum += s;
     }
-    // reduction over the 100 interior pixels (k = interior index i, 4 k-steps of 32; rows i >= 100
-    // read halo pixel 0 of dY, which is zero, so they add nothing; their X row is pixel 13 so that
-    // every tap shift stays inside the plane).
-    // dY pixel: pp = (i/10 + 1)*12 + i%10 + 1 ; matching X pixel for tap (dy,dx): pp + (dy-1)*12 + (dx-1).
+    // reduction over the 100 interior pixels (k = interior index i, 4 k-steps of 32; rows i >= 100 read the
+    // zero row of dY, so they add nothing; their X row is pixel 0 so that every tap shift stays inside the
+    // plane).  X pixel for dY pixel i and tap (dy,dx): interior_pp(i) + (dy-1)*12 + (dx-1).
     constexpr int KSTEPS = (NPIX + 31) / 32;
     const int t16 = lane & 15, q = t16 >> 2, pq = t16 & 3;
     const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
 #pragma unroll 1
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
-      const int py_lo = i_lo < NPIX ? interior_pp(i_lo) : 0;
-      const int py_hi = i_hi < NPIX ? interior_pp(i_hi) : 0;
-      const int px_lo = (i_lo < NPIX ? py_lo : PAD_W + 1) - PAD_W - 1;  // tap (dy, dx) = (0, 0)
-      const int px_hi = (i_hi < NPIX ? py_hi : PAD_W + 1) - PAD_W - 1;
-      const uint32_t ya_lo = ys_a + py_lo * row_stride<COUT>() + lane_col + 2 * co0;
-      const uint32_t ya_hi = ys_a + py_hi * row_stride<COUT>() + lane_col + 2 * co0;
-      const uint32_t xa_lo = xs_a + px_lo * row_stride<NCI>() + lane_col + 32 * nt0;
-      const uint32_t xa_hi = xs_a + px_hi * row_stride<NCI>() + lane_col + 32 * nt0;
-      const bf8 ah = tr_frag<0>(ya_lo, ya_hi);
-      bf8 al;
-      if (SPLIT == 3) al = tr_frag<YPL>(ya_lo, ya_hi);
-      auto tap_fn = [&](auto TC) {
+      const int px_lo = i_lo < NPIX ? interior_pp(i_lo) - PAD_W - 1 : 0;  // tap (dy, dx) = (0, 0)
+      const int px_hi = i_hi < NPIX ? interior_pp(i_hi) - PAD_W - 1 : 0;
+      const uint32_t ya_lo = ys_a + min(i_lo, NPIX) * YS + lane_col + 2 * co0w;
+      const uint32_t ya_hi = ys_a + min(i_hi, NPIX) * YS + lane_col + 2 * co0w;
+      const uint32_t xa_lo = xs_a + px_lo * row_stride<NCI>() + lane_col + 32 * wci;
+      const uint32_t xa_hi = xs_a + px_hi * row_stride<NCI>() + lane_col + 32 * wci;
+      bf8 ah[NCOW], al[NCOW];
+      static_for<NCOW>([&](auto JC) {
+        constexpr int j = decltype(JC)::value;
+        ah[j] = tr_frag<32 * j>(ya_lo, ya_hi);
+        if (SPLIT == 3) al[j] = tr_frag<YPL + 32 * j>(ya_lo, ya_hi);
+      });
+      bf8 bh[2], bl[2];
+      auto read_b = [&](auto TC) {
         constexpr int tap = decltype(TC)::value;
         constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * row_stride<NCI>();  // tap shift in LDS bytes
-        bf8 bh[NTW], bl[NTW];
-        auto rd = [&](auto JC) {
-          constexpr int j = decltype(JC)::value;
-          if constexpr (j < NTW) {
-            bh[j] = tr_frag<XO + 32 * j>(xa_lo, xa_hi);
-            if (SPLIT == 3) bl[j] = tr_frag<XPL + XO + 32 * j>(xa_lo, xa_hi);
-          }
-        };
-        rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{});
-        rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bh[tap & 1] = tr_frag<XO>(xa_lo, xa_hi);
+        if (SPLIT == 3) bl[tap & 1] = tr_frag<XPL + XO>(xa_lo, xa_hi);
+      };
+      read_b(std::integral_constant<int, 0>{});
+      static_for<9>([&](auto TC) {
+        constexpr int tap = decltype(TC)::value;
+        if constexpr (tap < 8) {
+          read_b(std::integral_constant<int, tap + 1>{});
+          // LDS returns in order: all but the reads just issued (2 ds_read per fragment) have landed
+          if (SPLIT == 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
+        for (int j = 0; j < NCOW; ++j) {
           if (SPLIT == 3) {
-            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[tap][j], 0, 0, 0);
-            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[tap][j], 0, 0, 0);
+            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
+            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl[tap & 1], acc[tap][j], 0, 0, 0);
           }
-          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[tap][j], 0, 0, 0);
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
         }
-      };
-      tap_fn(std::integral_constant<int, 0>{}); tap_fn(std::integral_constant<int, 1>{});
-      tap_fn(std::integral_constant<int, 2>{}); tap_fn(std::integral_constant<int, 3>{});
-      tap_fn(std::integral_constant<int, 4>{}); tap_fn(std::integral_constant<int, 5>{});
-      tap_fn(std::integral_constant<int, 6>{}); tap_fn(std::integral_constant<int, 7>{});
-      tap_fn(std::integral_constant<int, 8>{});
+      });
     }
   }
 
   // partial sums of this patch slice -> workspace (plain stores; a second kernel adds the slices
   // in a fixed order, so gradients are bitwise reproducible and no float atomics are needed).
-  // acc[tap][j][r] = dW[co0 + 4 g + r][ci_base + 16 (nt0 + j) + lane&15][tap]; the partial slab is laid out
-  // [tap][co][ci] so that the 16 lanes of a fragment row store 64 contiguous bytes (a [co][ci][tap]
+  // acc[tap][j][r] = dW[co_base + co0w + 16 j + 4 g + r][ci_base + 16 wci + lane&15][tap]; the partial slab is
+  // laid out [tap][co][ci] so that the 16 lanes of a fragment row store 64 contiguous bytes (a [co][ci][tap]
   // slab makes every 4-byte store its own HBM transaction: PMC WRITE_SIZE was 20x the slab size)
   float *dwp = a.dw_part + (long)blockIdx.y * COUT * CIN * 9;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
+    for (int j = 0; j < NCOW; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = co0 + 4 * g + r, ci = ci_base + 16 * (nt0 + j) + (lane & 15);
+        const int co = co_base + co0w + 16 * j + 4 * g + r, ci = ci_base + 16 * wci + (lane & 15);
         dwp[((long)tap * COUT + co) * CIN + ci] = acc[tap][j][r];
       }
-  // bias partials: reduce the 512/COUT pixel parts of each channel through LDS
+  // bias partials: reduce the 256/NCO pixel parts of each channel through LDS
   __syncthreads();
   float *red = reinterpret_cast<float *>(lds);
   red[tid] = dbsum;
   __syncthreads();
-  if (tid < COUT) {
+  if (tid < NCO) {
     float s = 0.f;
-    for (int part = 0; part < 512 / COUT; ++part) s += red[part * COUT + tid];
-    a.db_part[((long)blockIdx.y * NGRP + grp) * COUT + tid] = s;
+    for (int part = 0; part < 256 / NCO; ++part) s += red[part * NCO + tid];
+    a.db_part[((long)blockIdx.y * NGRP_CI + grp_ci) * COUT + co_base + tid] = s;
   }
 }
 
@@ -674,13 +727,13 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
   return launch_conv_ppw<SPLIT, CIN, COUT, MODE, 1>(a, s);
 }
 
-// input channels per workgroup: 64 keeps 9 taps x 4 ci tiles = 144 accumulator registers per lane
+// input channels per workgroup (one 16-channel tile per wave)
 constexpr int wgrad_nci(int cin) { return cin > 64 ? 64 : cin; }
 
 template <int SPLIT, int CIN, int COUT>
 int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
   constexpr int NCI = wgrad_nci(CIN);
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (plane_bytes<NCI>() + plane_bytes<COUT>());
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (plane_bytes<NCI>() + YROWS * row_stride<WG_NCO>());
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>,
@@ -690,7 +743,8 @@ int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>), dim3(CIN / NCI, nblk), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>), dim3((CIN / NCI) * (COUT / WG_NCO), nblk), dim3(256),
+                     lds, s, a);
   return check_launch();
 }
 
@@ -766,9 +820,9 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
 static int wgrad_groups(int cin) { return cin / wgrad_nci(cin); }
 
 static int wgrad_slices(int P, int cin, int cout, int split) {
-  const size_t lds = (size_t)(split == 3 ? 2 : 1) * NPAD * ((size_t)(wgrad_nci(cin) + cout) * 2 + 32);
-  const int per_cu = lds <= 80 * 1024 ? 2 : 1;  // workgroups of 512 threads per CU
-  int n = 256 * per_cu / wgrad_groups(cin);     // one workgroup per (slice, ci group)
+  (void)split;
+  const int groups = wgrad_groups(cin) * (cout / WG_NCO);  // workgroups per slice
+  int n = 256 * 2 / (groups < 1 ? 1 : groups);             // two workgroups of 256 threads per CU
   return n > P ? P : n;
 }
 
