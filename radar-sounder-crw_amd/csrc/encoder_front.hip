@@ -27,13 +27,22 @@ typedef __attribute__((address_space(3))) char *lds_cp;
 __device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
+// Workgroup barrier that makes LDS traffic visible but does NOT drain outstanding global loads
+// (__syncthreads() waits for vmcnt(0), which would expose the latency of the next patch's prefetch).
+// Only for phases whose cross-wave communication goes through LDS.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // geometry
-constexpr int XW = 16, XPW = 18;           // input patch, padded by 1
+constexpr int XPW = 18;                    // 16x16 input patch, padded by 1
 constexpr int C1W = 14, C1N = C1W * C1W;   // conv1 output 14x14
 constexpr int A1W = 13, A1PW = 15;         // pool1 output 13x13, padded by 1 -> 15x15
 constexpr int C2W = 11, C2N = C2W * C2W;   // conv2 output 11x11 (121)
 constexpr int OW = 10, ON = 100;           // pool2 output
 constexpr int D2PW = 19;                   // conv2-output gradient padded by 4 (for backward-data)
+// Those planes (and the backward weights) are stored as two 16-channel halves of 32-byte rows: with 64-byte rows
+// the ds_read_b128 lane groups of an MFMA fragment read (lanes {0-3,12-15,20-27}, ...) collide in the LDS banks;
+// with [half][row][32 B] the 16 lanes of a group cover all 64 banks (MI355X_MICROARCH.md, LDS table).
+constexpr int D2HALF = D2PW * D2PW * 32;   // bytes per half plane
 constexpr int KS2 = 7;                     // conv2 k-steps (28 taps, 25 real)
 constexpr int NTH = 1024, NWV = NTH / 64;  // 16 waves per workgroup: the stage is LDS-latency bound, one
                                            // 144 KB workgroup per CU, so latency is hidden by waves, not by workgroups
@@ -50,35 +59,34 @@ struct FrontArgs {
 // ---- shared forward pieces ----------------------------------------------------------------------
 struct FwdLds {
   float *xs;      // [cin][18][18]
-  float *w1;      // [8][cin][25] + b1[8]
+  float *w1;      // [cin][25][8 co] + b1[8]
   float *c1r;     // [196][8]
   char *a1h, *a1l;  // [225][8] bf16 (16 B per pixel)
   char *w2h, *w2l;  // [7][32][32] bf16
   float *c2r;     // [121][32]
 };
 
-__device__ inline void load_patch(const float *__restrict__ x, int cin, float *xs, int tid) {
-  for (int e = tid; e < cin * 256; e += NTH) {
-    const int c = e >> 8, r = (e >> 4) & 15, col = e & 15;
-    xs[(c * XPW + r + 1) * XPW + col + 1] = x[e];
-  }
-}
-
-// conv1 + bias + ReLU: thread = (output pixel, channel pair): 196 x 4 of the 1024 threads
+// conv1 + bias + ReLU: thread = (output pixel, 4 of the 8 channels): 392 threads.  The LDS weights are laid out
+// [ci][tap][8 co] so the four weights of a tap are one 16-byte broadcast read: 2 LDS reads per 4 FMAs.
 __device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
-  if (tid < C1N * 4) {
-    const int pix = tid >> 2, c0 = 2 * (tid & 3);
+  if (tid < C1N * 2) {
+    const int pix = tid >> 1, c0 = 4 * (tid & 1);
     const int y = pix / C1W, xx = pix % C1W;
-    float acc0 = L.w1[8 * cin * 25 + c0], acc1 = L.w1[8 * cin * 25 + c0 + 1];
-    for (int ci = 0; ci < cin; ++ci)
+    float4 acc = *reinterpret_cast<const float4 *>(L.w1 + 8 * cin * 25 + c0);
+    for (int ci = 0; ci < cin; ++ci) {
+      const float *xs = L.xs + (ci * XPW + y) * XPW + xx;
+      const float *w = L.w1 + ci * 25 * 8 + c0;
 #pragma unroll
       for (int t = 0; t < 25; ++t) {
-        const float v = L.xs[(ci * XPW + y + t / 5) * XPW + xx + t % 5];
-        acc0 = fmaf(v, L.w1[(c0 * cin + ci) * 25 + t], acc0);
-        acc1 = fmaf(v, L.w1[((c0 + 1) * cin + ci) * 25 + t], acc1);
+        const float v = xs[(t / 5) * XPW + t % 5];
+        const float4 wv = *reinterpret_cast<const float4 *>(w + t * 8);
+        acc.x = fmaf(v, wv.x, acc.x);
+        acc.y = fmaf(v, wv.y, acc.y);
+        acc.z = fmaf(v, wv.z, acc.z);
+        acc.w = fmaf(v, wv.w, acc.w);
       }
-    L.c1r[pix * 8 + c0] = fmaxf(acc0, 0.f);
-    L.c1r[pix * 8 + c0 + 1] = fmaxf(acc1, 0.f);
+    }
+    *reinterpret_cast<float4 *>(L.c1r + pix * 8 + c0) = float4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
   }
 }
 
@@ -147,7 +155,10 @@ __device__ inline FwdLds carve_fwd(char *&p, int cin) {
 template <int SPLIT>
 __device__ inline void stage_constants(const FwdLds &L, const FrontArgs &a, int tid) {
   for (int e = tid; e < a.cin * XPW * XPW; e += NTH) L.xs[e] = 0.f;  // zero border of the padded patch
-  for (int e = tid; e < 8 * a.cin * 25; e += NTH) L.w1[e] = a.w1[e];
+  for (int e = tid; e < 8 * a.cin * 25; e += NTH) {  // [co][ci][tap] -> [ci][tap][co]
+    const int t = e % 25, ci = (e / 25) % a.cin, co = e / (25 * a.cin);
+    L.w1[(ci * 25 + t) * 8 + co] = a.w1[e];
+  }
   if (tid < 8) L.w1[8 * a.cin * 25 + tid] = a.b1[tid];
   for (int e = tid; e < A1PW * A1PW * 4; e += NTH) {  // zero halo (and interior) of the a1 planes
     reinterpret_cast<uint32_t *>(L.a1h)[e] = 0;
@@ -167,15 +178,19 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
   const int tid = threadIdx.x;
   stage_constants<SPLIT>(L, a, tid);
   __syncthreads();
+  // the next patch (cin*256 <= 512 floats, one per thread) is fetched while the current one is processed
+  const int nx = a.cin * 256;
+  float x_r = blockIdx.x < a.P ? a.x[(long)blockIdx.x * nx + min(tid, nx - 1)] : 0.f;
   for (int pt = blockIdx.x; pt < a.P; pt += gridDim.x) {
-    load_patch(a.x + (long)pt * a.cin * 256, a.cin, L.xs, tid);
-    __syncthreads();
+    if (tid < nx) L.xs[((tid >> 8) * XPW + ((tid >> 4) & 15) + 1) * XPW + (tid & 15) + 1] = x_r;
+    if (pt + (int)gridDim.x < a.P) x_r = a.x[(long)(pt + gridDim.x) * nx + min(tid, nx - 1)];
+    lds_barrier();
     conv1_relu(L, a.cin, tid);
-    __syncthreads();
+    lds_barrier();
     pool1<SPLIT>(L, tid);
-    __syncthreads();
+    lds_barrier();
     conv2_relu<SPLIT>(L, a.b2, tid);
-    __syncthreads();
+    lds_barrier();
     // maxpool 2x2/1 -> output planes [100][32]
     for (int e = tid; e < ON * 32; e += NTH) {
       const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
@@ -217,7 +232,19 @@ struct FrontBwdArgs {
   const float *dy;           // [P][100][32] fp32 gradient of the pool2 output
   float *part;               // [nslice][PART] partial sums: dW2 [32][8][25], db2 [32], dW1 [8][cin][25], db1 [8]
   int patches_per_block;
+  long long *stamps;         // `make STAMPS=1` builds: [grid][NPHASE] cycles per phase summed over the slice (else null)
 };
+constexpr int NPHASE = 10;
+#ifdef CRW_CONV_STAMPS
+#define FRONT_STAMP(k)                                                       \
+  if (a.stamps && tid == 0) {                                                \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();          \
+    phase_[k] += now_ - prev_;                                               \
+    prev_ = now_;                                                            \
+  }
+#else
+#define FRONT_STAMP(k)
+#endif
 
 __device__ inline s4v tr_read0(uint32_t lds_addr) {
   s4v v;
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   const FwdLds L = carve_fwd(p, cin);
   auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
   char *wbh = take(25 * 8 * 32 * 2), *wbl = take(25 * 8 * 32 * 2);
-  char *d2h = take(D2PW * D2PW * 64), *d2l = take(D2PW * D2PW * 64);  // dC2 (masked), padded by 4, [pix][32] bf16
+  char *d2h = take(2 * D2HALF), *d2l = take(2 * D2HALF);  // dC2 (masked), padded by 4, [co half][pix][16] bf16
   float *dyb = (float *)take(sizeof(float) * ON * 32);                // dy of this patch; later dA1 [169][8] + dC1 [196][8]
   float *dA1 = dyb, *dC1 = dyb + A1W * A1W * 8;
   static_assert(A1W * A1W * 8 + C1N * 8 <= ON * 32, "alias");
@@ -256,10 +283,13 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   stage_constants<SPLIT>(L, a.f, tid);
   for (int e = tid; e < 25 * 8 * 32 / 8; e += NTH) {
-    reinterpret_cast<uint4 *>(wbh)[e] = reinterpret_cast<const uint4 *>(a.w2bh)[e];
-    if (SPLIT == 3) reinterpret_cast<uint4 *>(wbl)[e] = reinterpret_cast<const uint4 *>(a.w2bl)[e];
+    // global [tap][8 ci][4 chunks of 8 co] -> LDS [tap][co half][8 ci][2 chunks]
+    const int ch = e & 3, ci = (e >> 2) & 7, tap = e >> 5;
+    const int d = ((tap * 2 + (ch >> 1)) * 8 + ci) * 2 + (ch & 1);
+    reinterpret_cast<uint4 *>(wbh)[d] = reinterpret_cast<const uint4 *>(a.w2bh)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(wbl)[d] = reinterpret_cast<const uint4 *>(a.w2bl)[e];
   }
-  for (int e = tid; e < D2PW * D2PW * 16; e += NTH) {  // zero the padded gradient planes once (halo stays zero)
+  for (int e = tid; e < 2 * D2HALF / 4; e += NTH) {  // zero the padded gradient planes once (halo stays zero)
     reinterpret_cast<uint32_t *>(d2h)[e] = 0;
     reinterpret_cast<uint32_t *>(d2l)[e] = 0;
   }
@@ -271,23 +301,46 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   wacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
   wacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   float db2 = 0.f, dw1 = 0.f, db1 = 0.f;
+  const int nout = 8 * cin * 25, npart = NTH / nout;  // conv1 weight gradient: outputs x pixel parts (200 x 5 | 400 x 2)
 
   const uint32_t d2h_a = (uint32_t)(uintptr_t)(lds_cp)d2h, d2l_a = (uint32_t)(uintptr_t)(lds_cp)d2l;
   const uint32_t a1h_a = (uint32_t)(uintptr_t)(lds_cp)L.a1h, a1l_a = (uint32_t)(uintptr_t)(lds_cp)L.a1l;
 
   const int p_begin = blockIdx.x * a.patches_per_block;
   const int p_end = min(a.f.P, p_begin + a.patches_per_block);
+#ifdef CRW_CONV_STAMPS
+  long long phase_[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prev_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  // x (cin*256 floats) and dy (3200 floats) of the NEXT patch are fetched into registers while the current
+  // one is processed, so no phase waits on HBM
+  constexpr int DYIT = (ON * 32 / 4 + NTH - 1) / NTH;  // float4 chunks of dy per thread (800 chunks)
+  float4 dy_r[DYIT];
+  float x_r = 0.f;                                      // cin*256 <= 512 floats: threads < cin*256 hold one each
+  auto fetch = [&](int pt) {
+    const float4 *dsrc = reinterpret_cast<const float4 *>(a.dy + (long)pt * ON * 32);
+#pragma unroll
+    for (int i = 0; i < DYIT; ++i) dy_r[i] = dsrc[min(tid + i * NTH, ON * 32 / 4 - 1)];
+    x_r = a.f.x[(long)pt * cin * 256 + min(tid, cin * 256 - 1)];
+  };
+  if (p_begin < p_end) fetch(p_begin);
   for (int pt = p_begin; pt < p_end; ++pt) {
     // ---- recompute the forward of this patch ---------------------------------------------------
-    load_patch(a.f.x + (long)pt * cin * 256, cin, L.xs, tid);
-    for (int e = tid; e < ON * 32; e += NTH) dyb[e] = a.dy[(long)pt * ON * 32 + e];
-    __syncthreads();
+    if (tid < cin * 256) L.xs[((tid >> 8) * XPW + ((tid >> 4) & 15) + 1) * XPW + (tid & 15) + 1] = x_r;
+#pragma unroll
+    for (int i = 0; i < DYIT; ++i)
+      if (tid + i * NTH < ON * 32 / 4) reinterpret_cast<float4 *>(dyb)[tid + i * NTH] = dy_r[i];
+    if (pt + 1 < p_end) fetch(pt + 1);
+    lds_barrier();
+    FRONT_STAMP(0)
     conv1_relu(L, cin, tid);
-    __syncthreads();
+    lds_barrier();
+    FRONT_STAMP(1)
     pool1<SPLIT>(L, tid);
-    __syncthreads();
+    lds_barrier();
+    FRONT_STAMP(2)
     conv2_relu<SPLIT>(L, a.f.b2, tid);
-    __syncthreads();
+    lds_barrier();
+    FRONT_STAMP(3)
 
     // ---- pool2 + ReLU2 backward: dC2[pix][co] (masked) -> padded bf16 planes, bias gradient ------
     for (int e = tid; e < C2N * 32; e += NTH) {
@@ -309,11 +362,12 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
       }
       db2 += gsum;  // thread t always meets channel t & 31
       const uint16_t h = f2bf(gsum);
-      const int o = ((y + 4) * D2PW + x + 4) * 64 + 2 * co;
+      const int o = (co >> 4) * D2HALF + ((y + 4) * D2PW + x + 4) * 32 + 2 * (co & 15);
       *reinterpret_cast<uint16_t *>(d2h + o) = h;
       if (SPLIT == 3) *reinterpret_cast<uint16_t *>(d2l + o) = f2bf(gsum - bf2f(h));
     }
-    __syncthreads();
+    lds_barrier();
+    FRONT_STAMP(4)
 
     // ---- conv2 weight gradient: dW2[co][ci][tap] += sum_pix dC2[pix][co] * a1pad[pix + tap][ci] -----
     {
@@ -325,8 +379,8 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
         const int y_lo = v_lo ? i_lo / C2W : 0, x_lo = v_lo ? i_lo % C2W : 0;
         const int y_hi = v_hi ? i_hi / C2W : 0, x_hi = v_hi ? i_hi % C2W : 0;
         // A: dC2^T, rows = pixels (padded plane index, or halo pixel 0 for dummy rows), 16 co per tile
-        const uint32_t ya_lo = (v_lo ? ((y_lo + 4) * D2PW + x_lo + 4) : 0) * 64 + 8 * (pq & 1) + 16 * (pq >> 1);
-        const uint32_t ya_hi = (v_hi ? ((y_hi + 4) * D2PW + x_hi + 4) : 0) * 64 + 8 * (pq & 1) + 16 * (pq >> 1);
+        const uint32_t ya_lo = (v_lo ? ((y_lo + 4) * D2PW + x_lo + 4) : 0) * 32 + 8 * (pq & 1) + 16 * (pq >> 1);
+        const uint32_t ya_hi = (v_hi ? ((y_hi + 4) * D2PW + x_hi + 4) : 0) * 32 + 8 * (pq & 1) + 16 * (pq >> 1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int tile = wave + NWV * u;
@@ -338,11 +392,11 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
             // B: a1 padded plane [pix][8 ci] (16 B rows): fragment columns 0-7 = tap 2nt, 8-15 = tap 2nt+1
             const uint32_t xa_lo = ((y_lo * A1PW + x_lo) + toff) * 16 + 8 * (pq & 1);
             const uint32_t xa_hi = ((y_hi * A1PW + x_hi) + toff) * 16 + 8 * (pq & 1);
-            const bf8 ah = tr_pair(d2h_a + ya_lo + 32 * i, d2h_a + ya_hi + 32 * i);
+            const bf8 ah = tr_pair(d2h_a + ya_lo + D2HALF * i, d2h_a + ya_hi + D2HALF * i);
             const bf8 bh = tr_pair(a1h_a + xa_lo, a1h_a + xa_hi);
             bf8 al, bl;
             if (SPLIT == 3) {
-              al = tr_pair(d2l_a + ya_lo + 32 * i, d2l_a + ya_hi + 32 * i);
+              al = tr_pair(d2l_a + ya_lo + D2HALF * i, d2l_a + ya_hi + D2HALF * i);
               bl = tr_pair(a1l_a + xa_lo, a1l_a + xa_hi);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -357,35 +411,40 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
       }
     }
 
+    FRONT_STAMP(5)
     // ---- conv2 backward-data: dA1[ya][xa][ci] = sum_{tap,co} dC2[ya - ty + 1][xa - tx + 1][co] W2[co][ci][tap] ----
     {
-      f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
+      // Only 8 of the 16 MFMA output columns are real (8 input channels), so for bf16x3 the idle columns carry
+      // a correction term: B columns 0-7 = Wh, 8-15 = Wl (lanes r16 >= 8 simply read the lo plane), hence
+      //   ah x [Wh | Wl] -> columns 0-7 = ah*Wh, 8-15 = ah*Wl        al x [Wh | ..] -> columns 0-7 = al*Wh
+      // two MFMAs and three LDS reads per tap instead of three and four; the halves meet in a lane shift.
+      f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f}, dacc1 = dacc;
       if (wave < 11) {  // 169 pixels -> 11 row tiles, one per wave (wave-uniform)
         int i = 16 * wave + r16;
         if (i >= A1W * A1W) i = 0;
         const int base = ((i / A1W) + 5) * D2PW + (i % A1W) + 5;  // padded dC2 pixel of tap (0,0); tap shifts by -(ty*19 + tx)
-#pragma unroll 5
+        // B: backward weights, LDS layout [tap][co half][8 ci][16 co]: lane (ci = r16 & 7, k chunk g = co 8g..8g+7)
+        const char *wb = ((SPLIT == 3 && r16 >= 8) ? wbl : wbh) + (g >> 1) * 256 + (r16 & 7) * 32 + (g & 1) * 16;
+        // taps shift the A pixel by -(ty*19 + tx); rebased so that every tap is a non-negative immediate
+        const char *ab = d2h + (g >> 1) * D2HALF + (base - (4 * D2PW + 4)) * 32 + (g & 1) * 16;
+        const long lo_a = d2l - d2h;
+#pragma unroll
         for (int tap = 0; tap < 25; ++tap) {
-          const int toff = (tap / 5) * D2PW + (tap % 5);
-          // B: backward weights [tap][ci][32 co]: lane (ci = r16, k = co 8g..8g+7); ci >= 8 are zero columns
-          const s8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-          bf8 bh = __builtin_bit_cast(bf8, z), bl = bh;
-          if (r16 < 8) {
-            const int o = ((tap * 8 + r16) * 32 + 8 * g) * 2;
-            bh = *reinterpret_cast<const bf8 *>(wbh + o);
-            if (SPLIT == 3) bl = *reinterpret_cast<const bf8 *>(wbl + o);
-          }
-          const int o = (base - toff) * 64 + 16 * g;
-          const bf8 ah = *reinterpret_cast<const bf8 *>(d2h + o);
+          const int arel = ((4 - tap / 5) * D2PW + (4 - tap % 5)) * 32;
+          const bf8 b = *reinterpret_cast<const bf8 *>(wb + tap * 512);
+          const bf8 ah = *reinterpret_cast<const bf8 *>(ab + arel);
           if (SPLIT == 3) {
-            const bf8 al = *reinterpret_cast<const bf8 *>(d2l + o);
-            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, dacc, 0, 0, 0);
-            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, dacc, 0, 0, 0);
+            const bf8 al = *reinterpret_cast<const bf8 *>(ab + lo_a + arel);
+            dacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, dacc1, 0, 0, 0);
           }
-          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, dacc, 0, 0, 0);
+          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, dacc, 0, 0, 0);
+        }
+        if (SPLIT == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dacc[r] += __shfl_down(dacc[r], 8, 64) + dacc1[r];  // lanes r16 < 8 are the ones stored
         }
       }
-      __syncthreads();  // dyb (aliased by dA1) is no longer read
+      lds_barrier();  // dyb (aliased by dA1) is no longer read
       if (wave < 11 && r16 < 8)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -393,7 +452,8 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
           if (i < A1W * A1W) dA1[i * 8 + r16] = dacc[r];
         }
     }
-    __syncthreads();
+    lds_barrier();
+    FRONT_STAMP(6)
 
     // ---- pool1 + ReLU1 backward -> dC1 [196][8]; then the d2 planes' interior is cleared for the next patch ----
     for (int e = tid; e < C1N * 8; e += NTH) {
@@ -412,24 +472,33 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
           }
       }
       dC1[e] = gsum;
+      db1 += gsum;  // thread t always meets channel t & 7
     }
-    __syncthreads();
+    lds_barrier();
+    FRONT_STAMP(7)
 
-    // ---- conv1 weight / bias gradient (VALU): thread t < 8*cin*25 owns dW1[co][ci][tap]; threads 1016.. own db1 ----
-    if (tid < 8 * cin * 25) {
-      const int tap = tid % 25, ci = (tid / 25) % cin, co = tid / (25 * cin);
+    // ---- conv1 weight gradient (VALU): thread (o, part) adds the pixel rows part, part + NPART, ... of output
+    // o = dW1[co][ci][tap] (whole rows: every LDS address is a base + immediate, the phase is bound by VALU
+    // issue otherwise); the NPART partial sums of an output meet at the very end of the kernel ----
+    if (tid < nout * npart) {
+      const int o = tid % nout, part = tid / nout;
+      const int tap = o % 25, ci = (o / 25) % cin, co = o / (25 * cin);
       const float *xs = L.xs + (ci * XPW + tap / 5) * XPW + tap % 5;
       float s = 0.f;
-      for (int pix = 0; pix < C1N; ++pix) s = fmaf(dC1[pix * 8 + co], xs[(pix / C1W) * XPW + pix % C1W], s);
+      for (int y = part; y < C1W; y += npart) {
+        const float *dr = dC1 + y * C1W * 8 + co, *xr = xs + y * XPW;
+#pragma unroll
+        for (int x = 0; x < C1W; ++x) s = fmaf(dr[x * 8], xr[x], s);
+      }
       dw1 += s;
-    } else if (tid >= NTH - 8) {
-      const int co = tid - (NTH - 8);
-      float s = 0.f;
-      for (int pix = 0; pix < C1N; ++pix) s += dC1[pix * 8 + co];
-      db1 += s;
     }
-    __syncthreads();  // next patch may overwrite xs / dyb
+    lds_barrier();  // next patch may overwrite xs / dyb
+    FRONT_STAMP(8)
   }
+#ifdef CRW_CONV_STAMPS
+  if (a.stamps && tid == 0)
+    for (int k = 0; k < NPHASE; ++k) a.stamps[(long)blockIdx.x * NPHASE + k] = phase_[k];
+#endif
 
   // ---- partial sums of this slice -> workspace ------------------------------------------------------
   const int PART = 32 * 8 * 25 + 32 + 8 * cin * 25 + 8;
@@ -453,8 +522,22 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     for (int k = 0; k < NTH / 32; ++k) s += red[tid + 32 * k];
     out[32 * 8 * 25 + tid] = s;
   }
-  if (tid < 8 * cin * 25) out[32 * 8 * 25 + 32 + tid] = dw1;
-  if (tid >= NTH - 8) out[32 * 8 * 25 + 32 + 8 * cin * 25 + (tid - (NTH - 8))] = db1;
+  __syncthreads();
+  red[tid] = dw1;
+  __syncthreads();
+  if (tid < nout) {
+    float s = 0.f;
+    for (int k = 0; k < npart; ++k) s += red[tid + nout * k];
+    out[32 * 8 * 25 + 32 + tid] = s;
+  }
+  __syncthreads();
+  red[tid] = db1;
+  __syncthreads();
+  if (tid < 8) {
+    float s = 0.f;
+    for (int k = 0; k < NTH / 8; ++k) s += red[tid + 8 * k];
+    out[32 * 8 * 25 + 32 + nout + tid] = s;
+  }
 }
 
 // out[e] = sum_k part[k * stride + e], e < n: one wave per output, lanes stride the slices, fixed
@@ -476,7 +559,7 @@ size_t fwd_lds_bytes(int cin) {
 }
 size_t bwd_lds_bytes(int cin) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return fwd_lds_bytes(cin) + 2 * r(25 * 8 * 32 * 2) + 2 * r(D2PW * D2PW * 64) + r(4 * ON * 32);
+  return fwd_lds_bytes(cin) + 2 * r(25 * 8 * 32 * 2) + 2 * r(2 * D2HALF) + r(4 * ON * 32);
 }
 int front_slices(int P) { return P < 256 ? P : 256; }  // one 144 KB workgroup per CU
 
@@ -485,7 +568,13 @@ int front_slices(int P) { return P < 256 ? P : 256; }  // one 144 KB workgroup p
 
 using namespace crw;
 
+long long *g_front_stamps = nullptr;  // diagnostics (make STAMPS=1)
+
 extern "C" {
+
+#ifdef CRW_CONV_STAMPS
+void crw_debug_front_stamps(long long *buf) { g_front_stamps = buf; }
+#endif
 
 // conv2 weight [32][8][5][5] fp32 -> forward planes [7][32][32] and backward planes [25][8][32] (bf16 hi[, lo])
 int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi, uint16_t *bwd_lo,
@@ -529,7 +618,7 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
   if (ws_bytes < crw_enc_front_ws_bytes(P, cin)) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int nslice = front_slices(P), ppb = (P + nslice - 1) / nslice;
-  FrontBwdArgs a{{x, w1, b1, w2_hi, w2_lo, b2, nullptr, nullptr, P, cin}, w2b_hi, w2b_lo, dy, (float *)ws, ppb};
+  FrontBwdArgs a{{x, w1, b1, w2_hi, w2_lo, b2, nullptr, nullptr, P, cin}, w2b_hi, w2b_lo, dy, (float *)ws, ppb, g_front_stamps};
   const size_t lds = bwd_lds_bytes(cin);
   static bool attr3 = false, attr1 = false;
   if (split == 3) {
