@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop"],
+    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared"],
                     help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
                          "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder; labelprop: BASELINE "
                          "config 5, MCoRDS-shaped 410x8192 radargram, user-seed label propagation (utils.propagate)")
@@ -238,6 +238,58 @@ def bench_chain(args):
           flush=True)
 
 
+def bench_shared(args):
+    """ALL overlapping items of one 512x4096 radargram (225 windows of 32
+    patch-columns) in one step, every patch-column encoded once (CRW.forward_columns), vs the same items
+    batched the reference way (each item re-encoded; measured on a batch of 8 and scaled)."""
+    import dataset as crw_dataset
+    import encoder as crw_encoder
+    import model as crw_model
+    ds = crw_dataset.RGDataset.synthetic(H_RG, W_RG, T_SEQ, PATCH, OVERLAP, seed=11)
+    cols = ds.columns()[None].cuda()
+    items8 = torch.stack([ds[i] for i in range(8)]).cuda()
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    net = crw_model.CRW(enc, TAU, False).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+
+    def timed(fn):
+        for _ in range(max(1, args.warmup)):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps, loss.item()
+
+    def step_shared():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net.forward_columns(cols, T_SEQ)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def step_items():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net(items8)
+        loss.backward()
+        opt.step()
+        return loss
+
+    dt_s, loss_s = timed(step_shared)
+    dt_i, _ = timed(step_items)
+    S = len(ds)
+    print(json.dumps({"metric": "overlapping items/sec (CRW fwd+bwd+Adam, shared column encoding)", "value": S / dt_s,
+                      "unit": "items/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_s * 1e3,
+                      "higher_is_better": True, "data": "synthetic", "dtype": "f32 (bf16x3 conv trunk)",
+                      "config": {"workload": f"{H_RG}x{W_RG} radargram, all {S} overlapping items [T={T_SEQ},N=63,16x16] per step; "
+                                             f"{cols.shape[1]} patch-columns encoded once", "loss": loss_s},
+                      "itemwise": {"ms_per_8_items": dt_i * 1e3, "items_per_s": 8 / dt_i,
+                                   "what": "same model, CRW.forward on 8 overlapping items (each item re-encoded)"},
+                      "speedup_vs_itemwise": (S / dt_s) / (8 / dt_i)}), flush=True)
+
+
 def bench_labelprop(args):
     """BASELINE config 5: 410x8192 radargram, 32x32 patches, overlap (24,0) -> [T,N] = [256,48]; labels of the
     first patch column propagated along-track (CXT_SIZE 80 -> exercises the truncation quirk, RADIUS 10,
@@ -318,6 +370,10 @@ def main():
         import crw_hip
         crw_hip.lib()
         return bench_chain(args)
+    if args.workload == "shared":
+        import crw_hip
+        crw_hip.lib()
+        return bench_shared(args)
     import dist as crw_dist
     rank, world, local = crw_dist.init_from_env("nccl")
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"

@@ -77,6 +77,21 @@ class RGDataset(Dataset):
     def __getitem__(self, index):
         return self._cut(index, self.pxw)
 
+    def columns(self, first=0, count=None):
+        """Patch-columns ``first .. first+count-1`` of the radargram as one [Tc, N, h, w] tensor (default: all
+        ``len(self) + length - 1`` of them).  Item ``i`` of the dataset is ``columns()[i : i + length]``, so
+        overlapping items can share one encoder pass (``CRW.forward_columns``, SURVEY.md section 8 row f1;
+        the reference re-encodes every item, src/dataset.py:19-39 + scripts/train.py:66-67)."""
+        total = len(self) + self.l - 1
+        count = total - first if count is None else count
+        if first < 0 or count < 1 or first + count > total:
+            raise IndexError(f'columns [{first}, {first + count}) outside [0, {total})')
+        c0 = (self.w - self.ow) * first
+        pxw = count * self.w - self.ow * (count - 1)
+        block = self.T[:self.pxh, c0:c0 + pxw]
+        patches = block.unfold(0, self.h, self.h - self.oh).unfold(1, self.w, self.w - self.ow)  # [N, Tc, h, w]
+        return patches.permute(1, 0, 2, 3).float()
+
     def get_smaller_item(self, index, small_length):
         # like the reference this permanently shortens the item length of the dataset
         self.small_pxw = self.pxw = small_length * self.w - self.ow * (small_length - 1)

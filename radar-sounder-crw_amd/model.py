@@ -76,3 +76,25 @@ class CRW(nn.Module):
         if self.only_a:
             return A
         return walk_loss(A, self.chain), A
+
+    def forward_columns(self, cols, length, stride=1):
+        """Shared-encoder training step over OVERLAPPING items (opt-in, not in
+        the reference).  ``cols`` float32 [B, Tc, N, h, w] are consecutive patch-columns of B radargrams
+        (``RGDataset.columns``); the items are the windows of ``length`` columns starting every ``stride``
+        columns.  Every patch-column is encoded ONCE and every column-to-column affinity is built once; only
+        the walks run per item.  Returns ``(loss, A_all[B, Tc-1, N, N])`` where ``loss`` (and, through
+        autograd, the encoder gradient) equals what ``forward`` gives on the batch of all those items --
+        the reference semantics for that batch, with up to ``length`` times less encoder work."""
+        B, Tc, N, H, W = cols.shape
+        if not 3 <= length <= Tc or stride < 1:
+            raise ValueError(f"need 3 <= length <= {Tc} columns and stride >= 1")
+        x = cols.reshape(-1, H, W).unsqueeze(1)
+        if self.pos_embed:
+            x = pos_embed(x)
+        emb = self.encoder(x).reshape(B, Tc, N, -1)
+        A_all = affinity(emb, self.tau)                           # [B, Tc-1, N, N]
+        win = A_all.unfold(1, length - 1, stride)                 # [B, S, N, N, length-1] (view)
+        A_items = win.permute(0, 1, 4, 2, 3).reshape(-1, length - 1, N, N)  # materialised per-item logits
+        if self.only_a:
+            return A_all
+        return walk_loss(A_items, self.chain), A_all

@@ -2,7 +2,8 @@
 """CRW training entrypoint -- same flags and defaults as the reference's scripts/train.py:17-37
 (--tune and the Ray-Tune branch are out of scope: third-party orchestration, SURVEY.md section 2
 row 10).  Additions: --data_path / --synthetic H W (the reference's dataset paths are private),
---steps (stop early), --save (skip writing the checkpoint when empty).
+--steps (stop early), --save (skip writing the checkpoint when empty), --shared_encode (a batch is
+--batch_size CONSECUTIVE overlapping items whose patch-columns are encoded once, CRW.forward_columns).
 
 Single GPU:   python radar-sounder-crw_amd/scripts/train.py --model 0 --synthetic 512 4096
 Multi GPU:    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -48,6 +49,8 @@ def get_args_parser():
     p.add_argument('--data_path', default=None, help='H x W radargram .pt file')
     p.add_argument('--synthetic', default=None, nargs=2, type=int, metavar=('H', 'W'))
     p.add_argument('--steps', default=0, type=int, help='stop after this many steps (0 = full epochs)')
+    p.add_argument('--shared_encode', action='store_true',
+                   help='batches of consecutive overlapping items share one encoder pass (needs --dataset_full)')
     p.add_argument('--save', default='', help='checkpoint path for encoder.state_dict() (default: '
                                               '<output_folder>/models/<output_name>.pt)')
     return p
@@ -70,6 +73,8 @@ def main(args):
     if args.batch_size % world:
         raise SystemExit(f'--batch_size {args.batch_size} must be a multiple of the number of ranks ({world})')
     per_rank = args.batch_size // world
+    if args.shared_encode and not hasattr(dataset, 'columns'):
+        raise SystemExit('--shared_encode needs the overlapping dataset (--dataset_full True)')
 
     optimizer = Adam(model.parameters(), lr=args.lr)
     bucket = crw_dist.FlatGradBucket(model.parameters())
@@ -81,12 +86,19 @@ def main(args):
         order = torch.randperm(len(dataset), generator=g).tolist()
         usable = len(order) // args.batch_size * args.batch_size
         mine = [order[i] for i in range(usable) if (i % args.batch_size) // per_rank == rank]
-        loader = DataLoader(Subset(dataset, mine), batch_size=per_rank, shuffle=False)
+        if args.shared_encode:
+            # batch b = items [b*batch_size, (b+1)*batch_size): rank r walks per_rank consecutive items whose
+            # per_rank + seq_length - 1 patch-columns are encoded once; batch order is shuffled per epoch
+            nb = len(dataset) // args.batch_size
+            loader = (dataset.columns(b * args.batch_size + rank * per_rank, per_rank + args.seq_length - 1)[None]
+                      for b in torch.randperm(nb, generator=g).tolist())
+        else:
+            loader = DataLoader(Subset(dataset, mine), batch_size=per_rank, shuffle=False)
         loss_epoch = []
         for seq in loader:
             seq = seq.to(device, non_blocking=True)
             bucket.zero()
-            loss, _ = model(seq)
+            loss, _ = model.forward_columns(seq, args.seq_length) if args.shared_encode else model(seq)
             loss.backward()
             bucket.all_reduce_mean()
             optimizer.step()

@@ -173,6 +173,45 @@ def test_full_model_matches_reference(hip, name, wname, convs):
     assert crw_model.CRW(enc, 0.01, bool(g["pos_embed"]), only_a=True).cuda()(dev(g["seq"])).shape == A.shape
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_shared_column_encoding_matches_itemwise_and_oracle(hip, stride):
+    """CRW.forward_columns (every patch-column encoded once, windows of the shared
+    affinity walked per item) == CRW.forward on the batch of overlapping items == the CPU oracle on
+    that batch (loss and encoder gradients)."""
+    import model as crw_model
+    import encoder as crw_encoder
+    import dataset as crw_dataset
+    from oracle import crw_oracle as orc
+    T = 5
+    ds = crw_dataset.RGDataset.synthetic(64, 192, T, (16, 16), (8, 0), seed=5)  # 8 items of [5, 7, 16, 16]
+    cols = ds.columns()                                                         # [12, 7, 16, 16]
+    items = torch.stack([ds[i] for i in range(0, len(ds), stride)])
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    loss_ref, _, _ = orc.crw_forward_torch(items, sd, 0.05)
+    loss_ref.backward()
+    net = crw_model.CRW(enc, 0.05, False).cuda()
+    grads = {}
+    for mode in ("items", "columns"):
+        net.zero_grad()
+        if mode == "items":
+            loss, A = net(items.cuda())
+        else:
+            loss, A = net.forward_columns(cols[None].cuda(), T, stride)
+            assert A.shape == (1, cols.shape[0] - 1, 7, 7)
+        assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()), mode
+        loss.backward()
+        grads[mode] = {k: p.grad.clone() for k, p in enc.named_parameters()}
+    for k, ref in sd.items():
+        r = ref.grad.numpy()
+        np.testing.assert_allclose(grads["columns"][k].cpu().numpy(), r, rtol=2e-2, atol=2e-3 * np.abs(r).max())
+        np.testing.assert_allclose(grads["columns"][k].cpu().numpy(), grads["items"][k].cpu().numpy(),
+                                   rtol=1e-3, atol=1e-4 * np.abs(r).max())
+    with pytest.raises(ValueError):
+        net.forward_columns(cols[None].cuda(), 2)
+
+
 def _to_planes_ref(t):
     """fp32 NCHW [P,C,10,10] -> fp32 channels-last [P,100,C] (what the bf16 planes represent)."""
     P, C = t.shape[:2]

@@ -138,3 +138,17 @@ def test_labelprop_config_surface():
     assert lp.context_index(0, 6) == [0, 2, 3, 4, 5]
     m = lp._band(6, 1, torch.device("cpu"))
     assert np.array_equal(m[0].numpy(), orc.band_bias(6, 3))
+
+
+def test_dataset_columns_are_the_items():
+    """RGDataset.columns()[i : i + length] == item i (the shared-encoder feed)."""
+    import dataset as crw_dataset
+    for overlap in ((8, 0), (8, 4)):
+        ds = crw_dataset.RGDataset.synthetic(64, 200, 5, (16, 16), overlap, seed=3)
+        cols = ds.columns()
+        assert cols.shape[0] == len(ds) + 4 and cols.shape[1:] == ds[0].shape[1:]
+        for i in range(len(ds)):
+            assert torch.equal(cols[i:i + 5], ds[i])
+        assert torch.equal(ds.columns(2, 6), cols[2:8])
+        with pytest.raises(IndexError):
+            ds.columns(3, cols.shape[0])
