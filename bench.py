@@ -42,10 +42,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared"],
+    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared", "dense"],
                     help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
                          "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder; labelprop: BASELINE "
-                         "config 5, MCoRDS-shaped 410x8192 radargram, user-seed label propagation (utils.propagate)")
+                         "config 5, MCoRDS-shaped 410x8192 radargram, user-seed label propagation (utils.propagate); "
+                         "shared: all 225 overlapping items of the radargram per step, patch-columns encoded once "
+                         "(SURVEY 8 f1); dense: shape family D of SURVEY 8(d) = the radargram workload at --overlap 15 0 "
+                         "(N = 497 nodes per column)")
     ap.add_argument("--nodes", type=int, default=4096, help="N of the chain workload")
     ap.add_argument("--walk", type=int, default=32, help="T (frames) of the chain workload")
     return ap.parse_args()
@@ -55,7 +58,7 @@ def make_batch(rank, device):
     import dataset as crw_dataset
     ds = crw_dataset.RGDataset.synthetic(H_RG, W_RG, T_SEQ, PATCH, OVERLAP, seed=11 + rank)
     items = [ds[i] for i in range(0, len(ds), T_SEQ)]  # non-overlapping items of one radargram
-    return torch.stack(items).contiguous().to(device)  # [8, 32, 63, 16, 16]
+    return torch.stack(items).contiguous().to(device)  # [8, 32, 63, 16, 16] ([8, 32, 497, 16, 16] for "dense")
 
 
 def chain_probe(n, batch, nprob, iters=50):
@@ -374,6 +377,10 @@ def main():
         import crw_hip
         crw_hip.lib()
         return bench_shared(args)
+    if args.workload == "dense":  # shape family D: same radargram, vertical patch stride 1 -> N = 497
+        global OVERLAP
+        OVERLAP = (15, 0)
+        args.no_probe = args.no_cpu_baseline = True
     import dist as crw_dist
     rank, world, local = crw_dist.init_from_env("nccl")
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
@@ -434,7 +441,7 @@ def main():
                       "bf16": "bf16 (conv3-5 operands), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else "torch"],
             "data": "synthetic",
             "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
-                                   f"[T={T},N={N},16x16] (patch 16x16, overlap (8,0)), tau={TAU}, "
+                                   f"[T={T},N={N},16x16] (patch 16x16, overlap {OVERLAP}), tau={TAU}, "
                                    f"{'CNN' if args.model == 0 else 'Resnet'} encoder, fwd+bwd+all-reduce+Adam",
                        "columns_per_step_per_gpu": cols_per_step, "parallelism": f"dp{world} (independent sequences)",
                        "chain": "fp32 MFMA 16x16x4, prefix form", "encoder_convs": args.convs, "loss": final_loss},
