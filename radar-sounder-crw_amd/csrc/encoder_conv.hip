@@ -28,6 +28,7 @@
 // fixed order (bitwise reproducible, no float atomics).
 #include "crw_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace crw {
 namespace {
@@ -142,6 +143,7 @@ struct ConvArgs {
   const float *dgap;         // MODE 1, optional [P][CIN]: the input gradient is dgap/100 gated by xh (= forward
                              // activation hi plane) instead of being read from xh/xl
   int P;
+  int first_gen;             // workgroups resident at launch (CUs x workgroups per CU): see stagger_first_generation
   long long *stamps;         // diagnostic builds only: [grid][5] s_memtime at phase boundaries (else null)
 };
 
@@ -172,6 +174,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     (void)k;
 #endif
   };
+  // interleave the co-resident workgroups: period ~ 2 x the MFMA cycles of one workgroup's k-loop
+  stagger_first_generation(2 * (9 * KCH) * MTW * NTW * SPLIT * 16, a.first_gen);
   stamp(0);
   // ---- patches -> LDS ----------------------------------------------------------------------------
 #pragma unroll
@@ -193,15 +197,27 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   __syncthreads();
   stamp(1);
 
-  // row tile mt, row r16 -> interior pixel i -> padded index of the tap-(0,0) source pixel
+  // row tile mt, row r16 -> interior pixel i -> LDS byte offset of this lane's 16-byte chunk of the tap-(0,0)
+  // source pixel (k-chunk g); a k-step adds a wave-uniform offset (tap shift + 64 bytes per 32 channels)
+  static_assert(PPW == 1, "the pipelined k-loop handles one patch per workgroup");
   const int wm = wave / WN, wn = wave % WN;
-  int pp0[MTW];
+  int abase[MTW];
 #pragma unroll
   for (int k = 0; k < MTW; ++k) {
     int i = 16 * (wm + WM * k) + r16;
     if (i >= NPIX) i = 0;  // dummy rows recompute pixel 0 and are dropped in the epilogue
-    pp0[k] = (i / IMG_W) * PAD_W + (i % IMG_W);
+    abase[k] = px_off<CIN>((i / IMG_W) * PAD_W + (i % IMG_W), g);
   }
+  auto tile_live = [&](int k) { return WM == 1 || wm + WM * k < MT; };  // wave-uniform
+  auto step_off = [&](int step) {
+    const int tap = step / KCH, cc = step % KCH;
+    return ((tap / 3) * PAD_W + (tap % 3)) * row_stride<CIN>() + 64 * cc;
+  };
+  auto read_a = [&](int soff, int k, bf8 &h, bf8 &l) {
+    const char *p = lds + abase[k] + soff;
+    h = *reinterpret_cast<const bf8 *>(p);
+    if (SPLIT == 3) l = *reinterpret_cast<const bf8 *>(p + PLANE);
+  };
 
   f32x4 acc[PPW][MTW][NTW];
 #pragma unroll
@@ -226,54 +242,70 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 
   constexpr int NSTEP = 9 * KCH;
   constexpr int AHEAD = 4;  // weight fragments are requested 4 k-steps before use
-  auto do_step = [&](int step, bf8 (&bhc)[NTW], bf8 (&blc)[NTW], bf8 (&bhn)[NTW], bf8 (&bln)[NTW]) {
+  // Activation fragments are read from LDS DIST row tiles before the MFMAs that consume them (the compiler,
+  // left alone, issues them one tile = 96 cycles ahead: less than the LDS latency, so a workgroup alone in
+  // its k-loop kept the matrix pipe only ~55 % busy).  The first DIST tiles of the NEXT k-step are read
+  // during the last tiles of this one and carried in nah/nal.
+  constexpr int DIST = MTW < 3 ? MTW : 3;
+  bf8 nah[DIST], nal[DIST];
+#pragma unroll
+  for (int k = 0; k < DIST; ++k)
+    if (tile_live(k)) read_a(step_off(0), k, nah[k], nal[k]);
+  auto do_step = [&](auto LAST, int step, bf8 (&bhc)[NTW], bf8 (&blc)[NTW], bf8 (&bhn)[NTW], bf8 (&bln)[NTW]) {
+    constexpr bool last = decltype(LAST)::value;
     if (step + AHEAD < NSTEP) load_b(step + AHEAD, bhn, bln);
-    const int tap = step / KCH, cc = step % KCH;
-    const int toff = (tap / 3) * PAD_W + (tap % 3);
+    const int so = step_off(step), so1 = step_off(step + 1);
+    bf8 ah[MTW], al[MTW];
 #pragma unroll
-    for (int q = 0; q < PPW; ++q)
+    for (int k = 0; k < DIST; ++k) {
+      ah[k] = nah[k];
+      al[k] = nal[k];
+    }
 #pragma unroll
-      for (int k = 0; k < MTW; ++k) {
-        if (WM == 1 || wm + WM * k < MT) {  // wave-uniform
-          const int pp = pp0[k] + toff;
-          const char *img = lds + q * PATCH;
-          const bf8 ah = *reinterpret_cast<const bf8 *>(img + px_off<CIN>(pp, 4 * cc + g));
-          bf8 al;
-          if (SPLIT == 3) al = *reinterpret_cast<const bf8 *>(img + PLANE + px_off<CIN>(pp, 4 * cc + g));
+    for (int k = 0; k < MTW; ++k) {
+      if (k + DIST < MTW) {
+        if (tile_live(k + DIST)) read_a(so, k + DIST, ah[k + DIST], al[k + DIST]);
+      } else if (!last) {
+        if (tile_live(k + DIST - MTW)) read_a(so1, k + DIST - MTW, nah[k + DIST - MTW], nal[k + DIST - MTW]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tile_live(k)) {
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            if (SPLIT == 3) {
-              acc[q][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhc[j], acc[q][k][j], 0, 0, 0);
-              acc[q][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blc[j], acc[q][k][j], 0, 0, 0);
-            }
-            acc[q][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhc[j], acc[q][k][j], 0, 0, 0);
+        for (int j = 0; j < NTW; ++j) {
+          if (SPLIT == 3) {
+            acc[0][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k], bhc[j], acc[0][k][j], 0, 0, 0);
+            acc[0][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], blc[j], acc[0][k][j], 0, 0, 0);
           }
+          acc[0][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], bhc[j], acc[0][k][j], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   // five register sets for the weight fragments, rotated with static indices (a run-time index would
   // send them to scratch): step s uses set s % 5 and refills set (s + 4) % 5, i.e. 4 k-steps of
-  // weight loads (16 KiB per wave in bf16x3) are in flight -- the kernel is bound by how many bytes
-  // per clock the CU can pull from L2, which scales with the requests kept outstanding.  Six sets
-  // measured faster per workgroup but push conv5 past 256 registers (one workgroup per CU: slower).
+  // weight loads (16 KiB per wave in bf16x3) are in flight.  Six sets measured faster per workgroup but
+  // push conv5 past 256 registers (one workgroup per CU: slower).
   bf8 bh0[NTW], bl0[NTW], bh1[NTW], bl1[NTW], bh2[NTW], bl2[NTW], bh3[NTW], bl3[NTW], bh4[NTW], bl4[NTW];
   load_b(0, bh0, bl0);
   load_b(1, bh1, bl1);
   load_b(2, bh2, bl2);
   load_b(3, bh3, bl3);
-  static_assert(NSTEP >= 9, "NSTEP");
+  static_assert(NSTEP >= 9 && NSTEP % 5 != 0, "NSTEP");  // the last k-step is one of the tail calls below
+  constexpr int TAIL = NSTEP % 5;
+  using std::integral_constant;
   int step = 0;
   for (; step + 5 <= NSTEP; step += 5) {
-    do_step(step, bh0, bl0, bh4, bl4);
-    do_step(step + 1, bh1, bl1, bh0, bl0);
-    do_step(step + 2, bh2, bl2, bh1, bl1);
-    do_step(step + 3, bh3, bl3, bh2, bl2);
-    do_step(step + 4, bh4, bl4, bh3, bl3);
+    do_step(integral_constant<bool, false>{}, step, bh0, bl0, bh4, bl4);
+    do_step(integral_constant<bool, false>{}, step + 1, bh1, bl1, bh0, bl0);
+    do_step(integral_constant<bool, false>{}, step + 2, bh2, bl2, bh1, bl1);
+    do_step(integral_constant<bool, false>{}, step + 3, bh3, bl3, bh2, bl2);
+    do_step(integral_constant<bool, false>{}, step + 4, bh4, bl4, bh3, bl3);
   }
-  if (NSTEP % 5 >= 1) do_step(step, bh0, bl0, bh4, bl4);
-  if (NSTEP % 5 >= 2) do_step(step + 1, bh1, bl1, bh0, bl0);
-  if (NSTEP % 5 >= 3) do_step(step + 2, bh2, bl2, bh1, bl1);
-  if (NSTEP % 5 >= 4) do_step(step + 3, bh3, bl3, bh2, bl2);
+  if (TAIL >= 1) do_step(integral_constant<bool, TAIL == 1>{}, step, bh0, bl0, bh4, bl4);
+  if (TAIL >= 2) do_step(integral_constant<bool, TAIL == 2>{}, step + 1, bh1, bl1, bh0, bl0);
+  if (TAIL >= 3) do_step(integral_constant<bool, TAIL == 3>{}, step + 2, bh2, bl2, bh1, bl1);
+  if (TAIL >= 4) do_step(integral_constant<bool, TAIL == 4>{}, step + 3, bh3, bl3, bh2, bl2);
 
   // ---- epilogue ----------------------------------------------------------------------------------
   // C/D map: acc[q][k][j][r] = out[patch p0+q][pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
@@ -381,6 +413,7 @@ struct WgradArgs {
   float *dw_part;             // [nslice][9 taps][COUT][CIN] fp32 partial sums (every element written)
   float *db_part;             // [nslice][CIN/NCI][COUT] fp32 partial sums
   int P, patches_per_block;
+  int first_gen;              // workgroups resident at launch (see stagger_first_generation)
 };
 
 template <int IMM>
@@ -453,6 +486,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int p_end = min(a.P, p_begin + a.patches_per_block);
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
 
+  // interleave the two co-resident workgroups (period = one patch: load + 4 k-steps of 9 x NCOW x SPLIT MFMAs)
+  stagger_first_generation(2 * 4 * 9 * NCOW * SPLIT * 16, a.first_gen);
   // zeroed once: the halo of the X images and the k-padding row of the dY planes
   zero_halo<NCI, 256>(xs, tid);
   if (SPLIT == 3) zero_halo<NCI, 256>(xs + XPL, tid);
@@ -641,15 +676,34 @@ __global__ __launch_bounds__(256) void slice_sum_wave_kernel(const float *__rest
   if (lane == 0) out[e] = s;
 }
 
-// same for the weight gradient: slabs are [tap][co*ci], the result is the framework layout [co*ci][tap]
+// same for the weight gradient: slabs are [tap][co*ci], the result is the framework layout [co*ci][tap].
+// A block owns 64 consecutive slab elements; its 4 waves each add a quarter of the slices (8 independent
+// loads in flight per lane), the quarters meet in LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void slice_sum_dw_kernel(const float *__restrict__ part, int nslice, int coci,
                                                            float *__restrict__ out) {
+  __shared__ float red[4][64];
   const long n = 9L * coci;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < nslice; ++k) s += part[(long)k * n + e];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + lane;
+  const int per = (nslice + 3) / 4, k0 = q * per, k1 = min(nslice, k0 + per);
+  float s = 0.f;
+  if (e < n) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < k1; ++k) s += part[(long)k * n + e];
+  }
+  red[q][lane] = s;
+  __syncthreads();
+  if (q == 0 && e < n) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     const int tap = e / coci, cc = e % coci;
-    out[(long)cc * 9 + tap] = s;
+    out[(long)cc * 9 + tap] = t;
   }
 }
 
@@ -704,7 +758,10 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ 
 template <int SPLIT, int CIN, int COUT, int MODE, int PPW>
 int launch_conv_ppw(const ConvArgs &a, hipStream_t s) {
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
-  const size_t lds = (size_t)PPW * (SPLIT == 3 ? 2 : 1) * plane_bytes<CMAX>();
+  size_t lds = (size_t)PPW * (SPLIT == 3 ? 2 : 1) * plane_bytes<CMAX>();
+#ifdef CRW_CONV_STAMPS
+  if (const char *e = getenv("CRW_CONV_LDS_PAD")) lds += (size_t)atoi(e);  // diagnostics: force fewer workgroups per CU
+#endif
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>,
@@ -714,7 +771,9 @@ int launch_conv_ppw(const ConvArgs &a, hipStream_t s) {
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256), lds, s, a);
+  ConvArgs b = a;
+  b.first_gen = device_cus() * (int)((160 * 1024) / ((lds + 255) / 256 * 256));
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256), lds, s, b);
   return check_launch();
 }
 
@@ -801,7 +860,7 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
   if (split == 3 && (!w_lo || (!x_lo && !dgap))) return CRW_EINVAL;
   if (dgap && mode != 1) return CRW_EINVAL;
   if (!y_hi && !y_f32 && !gap) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, g_conv_stamps};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, 0, g_conv_stamps};
   hipStream_t s = (hipStream_t)stream;
 #define CRW_CONV_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
@@ -843,7 +902,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   const int nslice = wgrad_slices(P, cin, cout, split);
   const int ppb = (P + nslice - 1) / nslice;
   float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
-  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb};
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, 2 * device_cus()};
   int st = CRW_EINVAL;
 #define CRW_WG_CASE(CI, CO)                                                                  \
   if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);
@@ -853,7 +912,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
 #undef CRW_WG_CASE
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
-  hipLaunchKernelGGL(slice_sum_dw_kernel, dim3(ew_grid(nw)), dim3(256), 0, s, dw_part, nslice, cout * cin, dw);
+  hipLaunchKernelGGL(slice_sum_dw_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, dw_part, nslice, cout * cin, dw);
   hipLaunchKernelGGL(slice_sum_wave_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, db_part, nslice * wgrad_groups(cin),
                      (long)cout, cout, db);
   return check_launch();
