@@ -478,10 +478,12 @@ def main():
                         key = ("conv3x3_wgrad_kernel<3, 128, 128, 64>" if "wgrad" in k["kernel"] else
                                "conv3x3_kernel<3, 128, 128, 1, 1>" if "bwd-data" in k["kernel"] else
                                "conv3x3_kernel<3, 128, 128, 0, 1>")
-                        k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + pmc[key]["algorithmic_write_bytes"]
-                        k["traffic_note"] = ("HBM read bytes = 2*1024*FETCH_SIZE (gfx950 correction) from the committed PMC pass "
-                                             "+ algorithmic write bytes (WRITE_SIZE is polluted by the previous dispatch's write-back); "
-                                             f"read/algorithmic = {pmc[key]['read_over_algorithmic']}, L2 hit rate {pmc[key]['l2_hit_rate']}")
+                        wr = pmc[key].get("hbm_write_bytes", pmc[key]["algorithmic_write_bytes"])
+                        k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + wr
+                        k["traffic_note"] = ("HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_conv5.json): reads = "
+                                             "2*1024*FETCH_SIZE (gfx950 correction), writes = 1024*WRITE_SIZE where measured, else the "
+                                             f"algorithmic slab bytes; read/algorithmic = {pmc[key]['read_over_algorithmic']}, "
+                                             f"L2 hit rate {pmc[key]['l2_hit_rate']}")
             except Exception:
                 pass
             # the dominant kernel of the timed step = the hand-written kernel with the largest time per step
