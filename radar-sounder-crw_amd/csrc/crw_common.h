@@ -21,18 +21,6 @@ extern thread_local int g_last_hip_error;
 // only reports errors of our own launches.
 inline void clear_stale_error() { (void)hipGetLastError(); }
 
-// number of compute units of the current device (cached)
-inline int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-
 inline int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -137,23 +125,5 @@ int launch_loss_reduce(const float *terms, long n, float scale, float *loss, hip
 int launch_dAt(const float *At, const float *lse, const float *gloss, float coef, int nmat, int N, int Np,
                float *dAt, void *dAtb, hipStream_t s);
 int launch_unpad_At(const float *At, int K, int B, int N, int Np, float *out, hipStream_t s);
-
-// Co-resident workgroups of one kernel start together (workgroup i and i + #CUs land on the same CU within
-// ~200 cycles of each other) and, having identical phase lengths, stay in lockstep for the whole launch: both
-// load, both issue MFMAs, both store -- the matrix pipe idles while both are in a memory phase and is
-// oversubscribed while both compute.  The phase offset between them is neutrally stable, so delaying the
-// first-generation workgroup of LDS slot s by s/nslots of a period once keeps them interleaved for the
-// rest of the kernel.  The slot comes from HW_REG_LDS_ALLOC (base and size of this workgroup's LDS
-// allocation in 256-byte granules; the CU has 640).  `period` = shader cycles of one workgroup iteration.
-__device__ inline void stagger_first_generation(int period, int first_generation_workgroups) {
-  if ((int)(blockIdx.x + blockIdx.y * gridDim.x) >= first_generation_workgroups) return;
-  const unsigned a = __builtin_amdgcn_s_getreg((31 << 11) | 6);  // HW_REG_LDS_ALLOC, all 32 bits
-  const unsigned base = a & 0xfffu, size = (a >> 12) & 0xfffu;
-  if (base == 0 || size == 0) return;
-  const int nslots = 640 / (int)size, slot = (int)(base / size);
-  const long long wait = (long long)period * slot / (nslots > 0 ? nslots : 1);
-  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-  while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-}
 
 }  // namespace crw

@@ -143,7 +143,6 @@ struct ConvArgs {
   const float *dgap;         // MODE 1, optional [P][CIN]: the input gradient is dgap/100 gated by xh (= forward
                              // activation hi plane) instead of being read from xh/xl
   int P;
-  int first_gen;             // workgroups resident at launch (CUs x workgroups per CU): see stagger_first_generation
   long long *stamps;         // diagnostic builds only: [grid][5] s_memtime at phase boundaries (else null)
 };
 
@@ -174,8 +173,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     (void)k;
 #endif
   };
-  // interleave the co-resident workgroups: period ~ 2 x the MFMA cycles of one workgroup's k-loop
-  stagger_first_generation(2 * (9 * KCH) * MTW * NTW * SPLIT * 16, a.first_gen);
   stamp(0);
   // ---- patches -> LDS ----------------------------------------------------------------------------
 #pragma unroll
@@ -411,9 +408,11 @@ struct WgradArgs {
   const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
   const float *dgap;          // optional [P][COUT]: dY = dgap/100 gated by dyh (= forward activation hi plane)
   float *dw_part;             // [nslice][9 taps][COUT][CIN] fp32 partial sums (every element written)
-  float *db_part;             // [nslice][CIN/NCI][COUT] fp32 partial sums
+  float *db_part;             // [nslice][COUT] fp32 partial sums
   int P, patches_per_block;
-  int first_gen;              // workgroups resident at launch (see stagger_first_generation)
+  int xcd_map;                // 1: XCD-aware id -> (slice, group) mapping (needs the slice count to be a multiple of 8)
+  int stagger;                // shader cycles by which the workgroup in the CU's second LDS slot starts late (0 = off)
+  long long *stamps;          // `make STAMPS=1`: [workgroup][64]: 4 phase sums over the slice, then k-loop start times
 };
 
 template <int IMM>
@@ -441,7 +440,7 @@ __device__ inline void static_for(F &&f) {
     f(std::integral_constant<int, N - 1>{});
   }
 }
-
+// slice (1-D grid; id -> (slice, channel group) mapping below).
 // One workgroup (4 waves) = all 9 taps x WG_NCO output channels x NCI input channels of one patch
 // slice; blockIdx.x selects the slice, blockIdx.y the (ci group, co group).
 //   * A wave owns NCOW co tiles x ONE ci tile x 9 taps (36 accumulator tiles for conv4/conv5).  The dY
@@ -469,10 +468,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *xs = lds, *ys = lds + NPL * XPL;
 
-  // grid = (patch slices, channel groups): workgroup ids that differ by a multiple of 8 run on the same XCD, so
-  // with slices along x the (up to 4) groups of one slice share an L2 and the patch planes they all read
-  // come from HBM once (with groups along x, PMC showed every byte fetched twice, L2 hit rate 2 %)
-  const int grp_ci = blockIdx.y % NGRP_CI, grp_co = blockIdx.y / NGRP_CI;
+  // 1-D grid, workgroup id L -> (slice, channel group).  Workgroup L runs on XCD L % 8 and, for the ids
+  // resident at launch, on CU (L / 8) % 32 of that XCD (tools/ubench/dispatch_map.hip).  With
+  //   group = (L / 8) % NGRP,  slice = (L / 8 / NGRP) * 8 + L % 8
+  // the NGRP groups of a slice sit on neighbouring CUs of ONE XCD and read the slice's patches at the same
+  // time: the planes come from HBM once and are served to the other groups by that XCD's L2 (with groups
+  // on different XCDs PMC showed every byte fetched from HBM twice), while the two workgroups that share a
+  // CU (L and L + 256) belong to different slices.
+  constexpr int NGRP = NGRP_CI * (COUT / NCO);
+  const int wg_slice = a.xcd_map ? ((int)blockIdx.x / 8 / NGRP) * 8 + (int)blockIdx.x % 8 : (int)blockIdx.x / NGRP;
+  const int wg_grp = a.xcd_map ? ((int)blockIdx.x / 8) % NGRP : (int)blockIdx.x % NGRP;
+  const int grp_ci = wg_grp % NGRP_CI, grp_co = wg_grp / NGRP_CI;
   const int ci_base = grp_ci * NCI, co_base = grp_co * NCO;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int wci = wave % WCI, wco = wave / WCI;
@@ -483,14 +489,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < NCOW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbsum = 0.f;
+  // bias gradient on the matrix cores: dY^T fragments x an all-ones fragment = the pixel sums of 16 output
+  // channels in every column; only the waves of ci tile 0 in ci group 0 do it (8 extra MFMAs per k-step)
+  f32x4 accb[NCOW];
+#pragma unroll
+  for (int j = 0; j < NCOW; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool bias_wave = grp_ci == 0 && wci == 0;  // wave-uniform
 
-  const int p_begin = blockIdx.x * a.patches_per_block;
+  const int p_begin = wg_slice * a.patches_per_block;
   const int p_end = min(a.P, p_begin + a.patches_per_block);
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
 
-  // interleave the two co-resident workgroups (period = one patch: load + 4 k-steps of 9 x NCOW x SPLIT MFMAs)
-  stagger_first_generation(2 * 4 * 9 * NCOW * SPLIT * 16, a.first_gen);
+  if (a.stagger > 0) {  // second LDS slot of the CU (HW_REG_LDS_ALLOC base != 0) starts late
+    const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    if ((la & 0xfffu) != 0) {
+      const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+      while ((long long)__builtin_amdgcn_s_memtime() - t0 < a.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   // zeroed once: the halo of the X images and the k-padding row of the dY planes
   zero_halo<NCI, 256>(xs, tid);
   if (SPLIT == 3) zero_halo<NCI, 256>(xs + XPL, tid);
@@ -498,8 +514,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
 
   constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + 255) / 256;
   constexpr int YCH = NCO / 8, YTOT = NPIX * YCH, YIT = (YTOT + 255) / 256;
+#ifdef CRW_CONV_STAMPS
+  long long ph_[4] = {0, 0, 0, 0}, prev_ = (long long)__builtin_amdgcn_s_memtime();
+#define WG_STAMP(k) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); ph_[k] += n_ - prev_; prev_ = n_; }
+#else
+#define WG_STAMP(k)
+#endif
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();  // previous patch fully consumed
+    WG_STAMP(3)
     {
       // all global loads of the patch are issued before the first LDS store (one round trip)
       uint4 xv[NPL][XIT], yv[NPL][YIT];
@@ -567,18 +590,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
       }
     }
     __syncthreads();
-    // bias gradient: thread -> channel tid % NCO of this co group; the ci groups share out the pixels
-    {
-      constexpr int PARTS = 256 / NCO;
-      const int c = tid % NCO, part = tid / NCO;
-      float s = 0.f;
-      for (int i = part * NGRP_CI + grp_ci; i < NPIX; i += PARTS * NGRP_CI) {
-        const int o = i * YS + 2 * c;
-        s += bf2f(*reinterpret_cast<const uint16_t *>(ys + o));
-        if (SPLIT == 3) s += bf2f(*reinterpret_cast<const uint16_t *>(ys + YPL + o));
-      }
-      dbsum += s;
-    }
+    WG_STAMP(0)
+    WG_STAMP(1)
+#ifdef CRW_CONV_STAMPS
+    if (a.stamps && tid == 0 && p - p_begin < 60)  // absolute k-loop start times of the first patches (phase drift study)
+      a.stamps[(long)blockIdx.x * 64 + 4 + (p - p_begin)] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     // reduction over the 100 interior pixels (k = interior index i, 4 k-steps of 32; rows i >= 100 read the
     // zero row of dY, so they add nothing; their X row is pixel 0 so that every tap shift stays inside the
     // plane).  X pixel for dY pixel i and tap (dy,dx): interior_pp(i) + (dy-1)*12 + (dx-1).
@@ -619,6 +636,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (tap == 0) {
+          if (bias_wave) {
+            const s8v o = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};  // bf16 1.0
+            const bf8 ones = __builtin_bit_cast(bf8, o);
+#pragma unroll
+            for (int j = 0; j < NCOW; ++j) {
+              if (SPLIT == 3) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], ones, accb[j], 0, 0, 0);
+              accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], ones, accb[j], 0, 0, 0);
+            }
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NCOW; ++j) {
           if (SPLIT == 3) {
@@ -629,14 +657,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         }
       });
     }
+    WG_STAMP(2)
   }
+#ifdef CRW_CONV_STAMPS
+  if (a.stamps && tid == 0)
+    for (int k = 0; k < 4; ++k) a.stamps[(long)blockIdx.x * 64 + k] = ph_[k];
+#endif
 
   // partial sums of this patch slice -> workspace (plain stores; a second kernel adds the slices
   // in a fixed order, so gradients are bitwise reproducible and no float atomics are needed).
   // acc[tap][j][r] = dW[co_base + co0w + 16 j + 4 g + r][ci_base + 16 wci + lane&15][tap]; the partial slab is
   // laid out [tap][co][ci] so that the 16 lanes of a fragment row store 64 contiguous bytes (a [co][ci][tap]
   // slab makes every 4-byte store its own HBM transaction: PMC WRITE_SIZE was 20x the slab size)
-  float *dwp = a.dw_part + (long)blockIdx.x * COUT * CIN * 9;
+  float *dwp = a.dw_part + (long)wg_slice * COUT * CIN * 9;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -646,15 +679,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         const int co = co_base + co0w + 16 * j + 4 * g + r, ci = ci_base + 16 * wci + (lane & 15);
         dwp[((long)tap * COUT + co) * CIN + ci] = acc[tap][j][r];
       }
-  // bias partials: reduce the 256/NCO pixel parts of each channel through LDS
-  __syncthreads();
-  float *red = reinterpret_cast<float *>(lds);
-  red[tid] = dbsum;
-  __syncthreads();
-  if (tid < NCO) {
-    float s = 0.f;
-    for (int part = 0; part < 256 / NCO; ++part) s += red[part * NCO + tid];
-    a.db_part[((long)blockIdx.x * NGRP_CI + grp_ci) * COUT + co_base + tid] = s;
+  // bias partials: column 0 of accb[j] holds sum_pix dY[pix][co_base + co0w + 16 j + 4 g + r]
+  if (bias_wave && (lane & 15) == 0) {
+#pragma unroll
+    for (int j = 0; j < NCOW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a.db_part[(long)wg_slice * COUT + co_base + co0w + 16 * j + 4 * g + r] = accb[j][r];
   }
 }
 
@@ -774,9 +804,7 @@ int launch_conv_ppw(const ConvArgs &a, hipStream_t s) {
     }
     attr = true;
   }
-  ConvArgs b = a;
-  b.first_gen = device_cus() * (int)((160 * 1024) / ((lds + 255) / 256 * 256));
-  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, PPW>), dim3((a.P + PPW - 1) / PPW), dim3(256), lds, s, a);
   return check_launch();
 }
 
@@ -805,7 +833,7 @@ int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>), dim3(nblk, (CIN / NCI) * (COUT / WG_NCO)), dim3(256),
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>), dim3(nblk * (CIN / NCI) * (COUT / WG_NCO)), dim3(256),
                      lds, s, a);
   return check_launch();
 }
@@ -821,6 +849,13 @@ inline int ew_grid(long n) {
 using namespace crw;
 
 long long *g_conv_stamps = nullptr;  // set by crw_debug_conv_stamps (diagnostics)
+
+static int wgrad_stagger() {
+#ifdef CRW_CONV_STAMPS
+  if (const char *e = getenv("CRW_STAGGER")) return atoi(e);
+#endif
+  return 0;
+}
 
 extern "C" {
 
@@ -863,7 +898,7 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
   if (split == 3 && (!w_lo || (!x_lo && !dgap))) return CRW_EINVAL;
   if (dgap && mode != 1) return CRW_EINVAL;
   if (!y_hi && !y_f32 && !gap) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, 0, g_conv_stamps};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, g_conv_stamps};
   hipStream_t s = (hipStream_t)stream;
 #define CRW_CONV_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
@@ -905,7 +940,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   const int nslice = wgrad_slices(P, cin, cout, split);
   const int ppb = (P + nslice - 1) / nslice;
   float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
-  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, 2 * device_cus()};
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, nslice % 8 == 0 ? 1 : 0, wgrad_stagger(), g_conv_stamps};
   int st = CRW_EINVAL;
 #define CRW_WG_CASE(CI, CO)                                                                  \
   if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);
@@ -916,8 +951,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
   hipLaunchKernelGGL(slice_sum_dw_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, dw_part, nslice, cout * cin, dw);
-  hipLaunchKernelGGL(slice_sum_wave_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, db_part, nslice * wgrad_groups(cin),
-                     (long)cout, cout, db);
+  hipLaunchKernelGGL(slice_sum_wave_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, db_part, nslice, (long)cout, cout, db);
   return check_launch();
 }
 
