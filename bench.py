@@ -476,14 +476,24 @@ def main():
                 for k in kernels:
                     if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
                         key = ("conv3x3_wgrad_kernel<3, 128, 128, 64>" if "wgrad" in k["kernel"] else
-                               "conv3x3_kernel<3, 128, 128, 1, 1>" if "bwd-data" in k["kernel"] else
-                               "conv3x3_kernel<3, 128, 128, 0, 1>")
+                               "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
+                               "conv3x3_kernel<3, 128, 128, 0, 8>")
                         wr = pmc[key].get("hbm_write_bytes", pmc[key]["algorithmic_write_bytes"])
                         k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + wr
                         k["traffic_note"] = ("HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_conv5.json): reads = "
                                              "2*1024*FETCH_SIZE (gfx950 correction), writes = 1024*WRITE_SIZE where measured, else the "
                                              f"algorithmic slab bytes; read/algorithmic = {pmc[key]['read_over_algorithmic']}, "
                                              f"L2 hit rate {pmc[key]['l2_hit_rate']}")
+                util = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")))["kernels"]
+                for k in kernels:
+                    if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
+                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64>" if "wgrad" in k["kernel"] else
+                               "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
+                               "conv3x3_kernel<3, 128, 128, 0, 8>")
+                        k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
+                        k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
+                        k["pmc_note"] = ("committed PMC pass profiles/r01_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                                         "GRBM_GUI_ACTIVE/8) and the clock the chip held under this kernel (nominal 2.4 GHz)")
             except Exception:
                 pass
             # the dominant kernel of the timed step = the hand-written kernel with the largest time per step
