@@ -161,7 +161,7 @@ struct ConvArgs {
 // weight-fragment loads in flight (4-wave workgroups at 2 waves per SIMD measured ~65 % matrix-pipe
 // occupancy: each workgroup's phases are latency-bound on their own).
 template <int SPLIT, int CIN, int COUT, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   constexpr int PPW = 1, NT = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
@@ -426,7 +426,7 @@ __device__ inline s4v tr_read(uint32_t lds_addr) {
 }
 
 // transposed fragment: 8 reduction rows (pixels) x the 16 channels starting at channel C0.  a_lo / a_hi
-// are this lane's LDS byte addresses of fragment rows 8g+q and 8g+q+4 (already including the lane's
+// are this lane's LDS byte addresses of its two groups of 4 fragment rows (already including the lane's
 // 8*(pq&1) + 16*(pq>>1) column part); C0 and the plane offset enter as an instruction immediate.
 template <int IMM>
 __device__ inline bf8 tr_frag(uint32_t a_lo, uint32_t a_hi) {
@@ -457,14 +457,16 @@ __device__ inline void static_for(F &&f) {
 //     loading its next patch while the other computes.
 constexpr int WG_NCO = 64, YROWS = NPIX + 1;
 
-template <int SPLIT, int CIN, int COUT, int NCI>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
-  constexpr int NCO = WG_NCO;
+
+template <int SPLIT, int CIN, int COUT, int NCI, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int NCO = WG_NCO, NTH = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
-  constexpr int XPL = plane_bytes<NCI>();                  // X plane: 12x12 padded image, NCI channels
-  constexpr int YS = row_stride<NCO>(), YPL = YROWS * YS;  // dY plane: compact rows
+  // row strides 2C + 32: with the k-slot order below the 8 pixel rows of a transposing read tile the 64 banks
+  constexpr int XS = crs<NCI>(), XPL = NPAD * XS;          // X plane: 12x12 padded image, NCI channels
+  constexpr int YS = crs<NCO>(), YPL = YROWS * YS;         // dY plane: compact rows
   constexpr int NT = NCI / 16;                              // ci tiles of this group
-  constexpr int WCI = NT < 4 ? NT : 4, WCO = 4 / WCI;      // waves along ci tiles / co tiles
+  constexpr int WCI = NT < 4 ? NT : 4, WCO = NW / WCI;     // waves along ci tiles / co tiles
   constexpr int NCOW = NCO / 16 / WCO;                     // co tiles per wave
   static_assert(NT == WCI && COUT % NCO == 0 && CIN % NCI == 0, "tiling");
   constexpr int NGRP_CI = CIN / NCI;
@@ -511,12 +513,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
   }
   // zeroed once: the halo of the X images and the k-padding row of the dY planes
-  zero_halo<NCI, 256>(xs, tid);
-  if (SPLIT == 3) zero_halo<NCI, 256>(xs + XPL, tid);
+  zero_halo<NCI, NTH, XS>(xs, tid);
+  if (SPLIT == 3) zero_halo<NCI, NTH, XS>(xs + XPL, tid);
   if (tid < NPL * (YS / 16)) *reinterpret_cast<uint4 *>(ys + (tid / (YS / 16)) * YPL + NPIX * YS + 16 * (tid % (YS / 16))) = uint4{0, 0, 0, 0};
 
-  constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + 255) / 256;
-  constexpr int YCH = NCO / 8, YTOT = NPIX * YCH, YIT = (YTOT + 255) / 256;
+  constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + NTH - 1) / NTH;
+  constexpr int YCH = NCO / 8, YTOT = NPIX * YCH, YIT = (YTOT + NTH - 1) / NTH;
 #ifdef CRW_CONV_STAMPS
   long long ph_[4] = {0, 0, 0, 0}, prev_ = (long long)__builtin_amdgcn_s_memtime();
 #define WG_STAMP(k) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); ph_[k] += n_ - prev_; prev_ = n_; }
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         const uint16_t *src = (pl ? a.xl : a.xh) + (long)p * NPIX * CIN + ci_base;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-          const int c = min(tid + i * 256, XTOT - 1);  // clamped, unconditional (see PlaneLoad)
+          const int c = min(tid + i * NTH, XTOT - 1);  // clamped, unconditional (see PlaneLoad)
           xv[pl][i] = *reinterpret_cast<const uint4 *>(src + (long)(c / XCH) * CIN + 8 * (c % XCH));
         }
       }
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         const uint16_t *src = ((pl && !a.dgap) ? a.dyl : a.dyh) + (long)p * NPIX * COUT + co_base;
 #pragma unroll
         for (int i = 0; i < YIT; ++i) {
-          const int c = min(tid + i * 256, YTOT - 1);
+          const int c = min(tid + i * NTH, YTOT - 1);
           yv[pl][i] = *reinterpret_cast<const uint4 *>(src + (long)(c / YCH) * COUT + 8 * (c % YCH));
         }
       }
@@ -552,17 +554,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
       for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-          const int c = tid + i * 256;
-          if (XTOT % 256 == 0 || c < XTOT)
-            *reinterpret_cast<uint4 *>(xs + pl * XPL + px_off<NCI>(interior_pp(c / XCH), c % XCH)) = xv[pl][i];
+          const int c = tid + i * NTH;
+          if (XTOT % NTH == 0 || c < XTOT)
+            *reinterpret_cast<uint4 *>(xs + pl * XPL + interior_pp(c / XCH) * XS + 16 * (c % XCH)) = xv[pl][i];
         }
       if (a.dgap) {
         // dY[i][c] = dgap[c] / 100 where the forward activation (hi plane, in yv[0]) is non-zero
         const float *dg = a.dgap + (long)p * COUT + co_base;
 #pragma unroll
         for (int i = 0; i < YIT; ++i) {
-          const int c = tid + i * 256;
-          if (YTOT % 256 == 0 || c < YTOT) {
+          const int c = tid + i * NTH;
+          if (YTOT % NTH == 0 || c < YTOT) {
             const int ch = c % YCH;
             const float4 g0 = *reinterpret_cast<const float4 *>(dg + 8 * ch);
             const float4 g1 = *reinterpret_cast<const float4 *>(dg + 8 * ch + 4);
@@ -587,8 +589,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
           for (int i = 0; i < YIT; ++i) {
-            const int c = tid + i * 256;
-            if (YTOT % 256 == 0 || c < YTOT) *reinterpret_cast<uint4 *>(ys + pl * YPL + (c / YCH) * YS + 16 * (c % YCH)) = yv[pl][i];
+            const int c = tid + i * NTH;
+            if (YTOT % NTH == 0 || c < YTOT) *reinterpret_cast<uint4 *>(ys + pl * YPL + (c / YCH) * YS + 16 * (c % YCH)) = yv[pl][i];
           }
       }
     }
@@ -607,13 +609,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
 #pragma unroll 1
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
+      // k-slot order: lane group g holds pixels 32 ks + 4 g + q (first read) and + 16 (second read), so the 32 lanes
+      // of one ds_read_b64_tr_b16 bank group touch 8 CONSECUTIVE pixel rows (conflict-free on the 2C+32 stride);
+      // dY and X use the same order, so the contraction over the 32 pixels is unchanged
+      const int i_lo = 32 * ks + 4 * g + q, i_hi = i_lo + 16;
       const int px_lo = i_lo < NPIX ? interior_pp(i_lo) - PAD_W - 1 : 0;  // tap (dy, dx) = (0, 0)
       const int px_hi = i_hi < NPIX ? interior_pp(i_hi) - PAD_W - 1 : 0;
       const uint32_t ya_lo = ys_a + min(i_lo, NPIX) * YS + lane_col + 2 * co0w;
       const uint32_t ya_hi = ys_a + min(i_hi, NPIX) * YS + lane_col + 2 * co0w;
-      const uint32_t xa_lo = xs_a + px_lo * row_stride<NCI>() + lane_col + 32 * wci;
-      const uint32_t xa_hi = xs_a + px_hi * row_stride<NCI>() + lane_col + 32 * wci;
+      const uint32_t xa_lo = xs_a + px_lo * XS + lane_col + 32 * wci;
+      const uint32_t xa_hi = xs_a + px_hi * XS + lane_col + 32 * wci;
       bf8 ah[NCOW], al[NCOW];
       static_for<NCOW>([&](auto JC) {
         constexpr int j = decltype(JC)::value;
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
       bf8 bh[2], bl[2];
       auto read_b = [&](auto TC) {
         constexpr int tap = decltype(TC)::value;
-        constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * row_stride<NCI>();  // tap shift in LDS bytes
+        constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * XS;  // tap shift in LDS bytes
         bh[tap & 1] = tr_frag<XO>(xa_lo, xa_hi);
         if (SPLIT == 3) bl[tap & 1] = tr_frag<XPL + XO>(xa_lo, xa_hi);
       };
@@ -825,19 +830,21 @@ constexpr int wgrad_nci(int cin) { return cin > 64 ? 64 : cin; }
 
 template <int SPLIT, int CIN, int COUT>
 int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
-  constexpr int NCI = wgrad_nci(CIN);
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (plane_bytes<NCI>() + YROWS * row_stride<WG_NCO>());
+  // measured (tools/probe_conv.py): hi/lo pairs are faster with 4 waves (144 accumulator registers per wave, 26
+  // fragment reads per 108 MFMAs), plain bf16 with 8 (4 waves per SIMD hide the load phase)
+  constexpr int NCI = wgrad_nci(CIN), NW = SPLIT == 3 ? 4 : 8;
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (NPAD * crs<NCI>() + YROWS * crs<WG_NCO>());
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>,
+    if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI, NW>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI>), dim3(nblk * (CIN / NCI) * (COUT / WG_NCO)), dim3(256),
-                     lds, s, a);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI, NW>), dim3(nblk * (CIN / NCI) * (COUT / WG_NCO)),
+                     dim3(NW * 64), lds, s, a);
   return check_launch();
 }
 
