@@ -475,7 +475,7 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))["kernels"]
                 for k in kernels:
                     if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
-                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64>" if "wgrad" in k["kernel"] else
+                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
                                "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
                                "conv3x3_kernel<3, 128, 128, 0, 8>")
                         wr = pmc[key].get("hbm_write_bytes", pmc[key]["algorithmic_write_bytes"])
@@ -487,7 +487,7 @@ def main():
                 util = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")))["kernels"]
                 for k in kernels:
                     if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
-                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64>" if "wgrad" in k["kernel"] else
+                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
                                "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
                                "conv3x3_kernel<3, 128, 128, 0, 8>")
                         k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]

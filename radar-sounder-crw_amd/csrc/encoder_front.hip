@@ -106,7 +106,7 @@ __device__ inline void pool1(const FwdLds &L, int tid) {
 
 // conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  16 output tiles (8 row x 2 column), one per wave.
 template <int SPLIT>
-__device__ inline void conv2_relu(const FwdLds &L, const float *__restrict__ b2, int tid) {
+__device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bias = b2[16 (wave & 1) + lane % 16]
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   const int mt = wave >> 1, j = wave & 1;
   int i0 = 16 * mt + r16;
@@ -130,7 +130,7 @@ __device__ inline void conv2_relu(const FwdLds &L, const float *__restrict__ b2,
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
   }
   const int co = 16 * j + r16;
-  const float b = b2[co];
+  const float b = bias;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 16 * mt + 4 * g + r;
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
   const int tid = threadIdx.x;
   stage_constants<SPLIT>(L, a, tid);
   __syncthreads();
+  const float b2r = a.b2[16 * ((tid >> 6) & 1) + (tid & 15)];  // read once: the barriers in the loop are memory clobbers
   // the next patch (cin*256 <= 512 floats, one per thread) is fetched while the current one is processed
   const int nx = a.cin * 256;
   float x_r = blockIdx.x < a.P ? a.x[(long)blockIdx.x * nx + min(tid, nx - 1)] : 0.f;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
     lds_barrier();
     pool1<SPLIT>(L, tid);
     lds_barrier();
-    conv2_relu<SPLIT>(L, a.b2, tid);
+    conv2_relu<SPLIT>(L, b2r, tid);
     lds_barrier();
     // maxpool 2x2/1 -> output planes [100][32]
     for (int e = tid; e < ON * 32; e += NTH) {
@@ -267,6 +268,43 @@ __device__ inline int argmax4(float a, float b, float c, float d) {
   return k;
 }
 
+// Gradient reaching pixel (y, x) of a W x W map through a 2x2/stride-1 max-pool whose (W-1) x (W-1) output has
+// gradient dout: the up to four windows containing the pixel route their gradient to it iff it is the FIRST
+// maximum of the window in row-major order (torch's tie rule, = argmax4 above).  The four windows only involve
+// the pixel's 3x3 neighbourhood, read once (8 LDS reads instead of 16).  in/dout: channel-interleaved with CS floats
+// per pixel; the caller has checked in[pixel] > 0 (ReLU).
+template <int W, int CS>
+__device__ inline float pool_bwd_pixel(const float *__restrict__ in, const float *__restrict__ dout, int y, int x, int c,
+                                       float mine) {
+  float nb[3][3];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = min(max(y + dy - 1, 0), W - 1), xx = min(max(x + dx - 1, 0), W - 1);  // clamped: only used by valid windows
+      nb[dy][dx] = (dy == 1 && dx == 1) ? mine : in[(yy * W + xx) * CS + c];
+    }
+  float gsum = 0.f;
+#pragma unroll
+  for (int dyw = 0; dyw < 2; ++dyw)
+#pragma unroll
+    for (int dxw = 0; dxw < 2; ++dxw) {
+      const int wy = y - dyw, wx = x - dxw;
+      if (wy >= 0 && wy < W - 1 && wx >= 0 && wx < W - 1) {
+        const int k = dyw * 2 + dxw;  // this pixel's position in the window
+        bool win = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j != k) {
+            const float v = nb[1 - dyw + (j >> 1)][1 - dxw + (j & 1)];
+            win = win && (j < k ? mine > v : mine >= v);
+          }
+        if (win) gsum += dout[(wy * (W - 1) + wx) * CS + c];
+      }
+    }
+  return gsum;
+}
+
 template <int SPLIT>
 __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -311,6 +349,7 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
 #ifdef CRW_CONV_STAMPS
   long long phase_[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prev_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
+  const float b2r = a.f.b2[16 * (wave & 1) + r16];  // read once: the barriers in the loop are memory clobbers
   // x (cin*256 floats) and dy (3200 floats) of the NEXT patch are fetched into registers while the current
   // one is processed, so no phase waits on HBM
   constexpr int DYIT = (ON * 32 / 4 + NTH - 1) / NTH;  // float4 chunks of dy per thread (800 chunks)
@@ -338,28 +377,15 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     pool1<SPLIT>(L, tid);
     lds_barrier();
     FRONT_STAMP(2)
-    conv2_relu<SPLIT>(L, a.f.b2, tid);
+    conv2_relu<SPLIT>(L, b2r, tid);
     lds_barrier();
     FRONT_STAMP(3)
 
     // ---- pool2 + ReLU2 backward: dC2[pix][co] (masked) -> padded bf16 planes, bias gradient ------
     for (int e = tid; e < C2N * 32; e += NTH) {
       const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
-      float gsum = 0.f;
       const float mine = L.c2r[e];
-      if (mine > 0.f) {
-        // windows (wy, wx) with wy in {y-1, y}, wx in {x-1, x} contain this pixel at position (y-wy, x-wx)
-#pragma unroll
-        for (int dyw = 0; dyw < 2; ++dyw)
-#pragma unroll
-          for (int dxw = 0; dxw < 2; ++dxw) {
-            const int wy = y - dyw, wx = x - dxw;
-            if (wy >= 0 && wy < OW && wx >= 0 && wx < OW) {
-              const float *s = L.c2r + (wy * C2W + wx) * 32 + co;
-              if (argmax4(s[0], s[32], s[C2W * 32], s[C2W * 32 + 32]) == dyw * 2 + dxw) gsum += dyb[(wy * OW + wx) * 32 + co];
-            }
-          }
-      }
+      const float gsum = mine > 0.f ? pool_bwd_pixel<C2W, 32>(L.c2r, dyb, y, x, co, mine) : 0.f;
       db2 += gsum;  // thread t always meets channel t & 31
       const uint16_t h = f2bf(gsum);
       const int o = (co >> 4) * D2HALF + ((y + 4) * D2PW + x + 4) * 32 + 2 * (co & 15);
@@ -458,19 +484,8 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     // ---- pool1 + ReLU1 backward -> dC1 [196][8]; then the d2 planes' interior is cleared for the next patch ----
     for (int e = tid; e < C1N * 8; e += NTH) {
       const int co = e & 7, pix = e >> 3, y = pix / C1W, x = pix % C1W;
-      float gsum = 0.f;
-      if (L.c1r[e] > 0.f) {
-#pragma unroll
-        for (int dyw = 0; dyw < 2; ++dyw)
-#pragma unroll
-          for (int dxw = 0; dxw < 2; ++dxw) {
-            const int wy = y - dyw, wx = x - dxw;
-            if (wy >= 0 && wy < A1W && wx >= 0 && wx < A1W) {
-              const float *s = L.c1r + (wy * C1W + wx) * 8 + co;
-              if (argmax4(s[0], s[8], s[C1W * 8], s[C1W * 8 + 8]) == dyw * 2 + dxw) gsum += dA1[(wy * A1W + wx) * 8 + co];
-            }
-          }
-      }
+      const float mine = L.c1r[e];
+      const float gsum = mine > 0.f ? pool_bwd_pixel<C1W, 8>(L.c1r, dA1, y, x, co, mine) : 0.f;
       dC1[e] = gsum;
       db1 += gsum;  // thread t always meets channel t & 7
     }
