@@ -73,12 +73,18 @@ def seed_labels(seg_ref, N):
 
 
 def change_point(xent):
-    """PELT(rbf, pen=5) on the column-to-column change of the metric (src/utils.py:125-132); like
-    the reference, any failure (here: `ruptures` not installed) yields None."""
-    diffs = (xent[:, :-1] - xent[:, 1:]).abs().sum(0)
+    """PELT(rbf, pen=5) on the column-to-column change of the metric, then `result[-2] + 5` clamped at 0
+    (src/utils.py:125-132).  Uses `ruptures` when it is importable, else the restatement of its published
+    algorithm in pelt.py (parity unpinned, see there); like the reference, any failure -- e.g. fewer than
+    two breakpoints -- yields None."""
+    diffs = (xent[:, :-1] - xent[:, 1:]).abs().sum(0).cpu().numpy()
     try:
-        import ruptures as rpt
-        result = rpt.Pelt(model="rbf").fit(diffs.cpu().numpy()).predict(pen=5)
+        try:
+            import ruptures as rpt
+            result = rpt.Pelt(model="rbf").fit(diffs).predict(pen=5)
+        except ImportError:
+            from pelt import pelt_rbf
+            result = pelt_rbf(diffs, pen=5)
         return max(0, int(result[-2] + 5))
     except Exception:
         return None

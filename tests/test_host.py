@@ -152,3 +152,24 @@ def test_dataset_columns_are_the_items():
         assert torch.equal(ds.columns(2, 6), cols[2:8])
         with pytest.raises(IndexError):
             ds.columns(3, cols.shape[0])
+
+
+def test_pelt_rbf_restatement():
+    """pelt.py (restated PELT + RBF kernel cost; parity with `ruptures` is unpinned): a clean mean shift is found
+    at a multiple of `jump`, a flat signal has no interior breakpoint, and utils.change_point applies the
+    reference's `result[-2] + 5` / None-on-failure convention (src/utils.py:125-132)."""
+    import pelt
+    import utils as crw_utils
+    rng = np.random.default_rng(0)
+    sig = np.concatenate([rng.normal(0, 0.1, 40), rng.normal(3, 0.1, 35)])
+    bk = pelt.pelt_rbf(sig, pen=5)
+    assert bk[-1] == len(sig) and 40 in bk
+    assert pelt.pelt_rbf(np.zeros(50), pen=5) == [50]
+    g = pelt.rbf_gram(sig)
+    assert np.allclose(np.diagonal(g), 1.0) and np.allclose(g, g.T) and g.min() >= np.exp(-100.0)
+    # xent [N, T-1] whose column-to-column change jumps at column 40: change_idx = breakpoint + 5
+    xent = torch.zeros(4, 77)
+    xent[:, 41:] = torch.arange(36).float().repeat(4, 1) % 2 * 3.0
+    ci = crw_utils.change_point(xent)
+    assert ci is not None and ci >= 5
+    assert crw_utils.change_point(torch.zeros(4, 30)) is None
