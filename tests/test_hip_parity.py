@@ -283,6 +283,55 @@ def test_encoder_conv_kernels_match_torch(hip, cin, cout, split):
     torch.testing.assert_close(db.cpu().double(), dyq.sum((0, 2, 3)), **wtol)
 
 
+@pytest.mark.parametrize("cin,cout", [(128, 128), (64, 128), (32, 64)])
+def test_encoder_kernels_full_size_by_replication(hip, cin, cout):
+    """BASELINE workload size (P = 16128 patches, where the weight gradient runs 128-512 patch slices with the
+    XCD-aware workgroup mapping) checked through a size-independent property: the batch is 8 distinct patches
+    replicated 2016 times, so every replica's conv output must equal the 8-patch run bit for bit and the weight /
+    bias gradients must be 2016x the 8-patch gradients; also the front-end kernels at that size."""
+    P0, reps, split = 8, 2016, 3
+    g = torch.Generator().manual_seed(cin)
+    xp = (torch.randn(P0, 100, cin, generator=g) * 0.5).cuda()
+    dyp = (torch.randn(P0, 100, cout, generator=g) * 0.5).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    fh, fl, bh, bl = hip.enc_pack_weights(w, split)
+    hl = lambda t: (t.bfloat16(), (t - t.bfloat16().float()).bfloat16())
+    (xh, xl), (dh, dl) = hl(xp), hl(dyp)
+    rep = lambda t: t.repeat(reps, 1, 1).contiguous()
+    y_s = hip.enc_conv3x3(0, split, xh, xl, fh, fl, cout, bias=b)
+    y_f = hip.enc_conv3x3(0, split, rep(xh), rep(xl), fh, fl, cout, bias=b)
+    d_s = hip.enc_conv3x3(1, split, dh, dl, bh, bl, cin, mask=xh)
+    d_f = hip.enc_conv3x3(1, split, rep(dh), rep(dl), bh, bl, cin, mask=rep(xh))
+    for small, full in ((y_s, y_f), (d_s, d_f)):
+        for pl in (0, 1):
+            v = full[pl].view(reps, P0, 100, -1)
+            assert torch.equal(v[0], small[pl]) and torch.equal(v[reps - 1], small[pl]) and torch.equal(v[reps // 2], small[pl])
+    dw_s, db_s = hip.enc_wgrad(split, dh, dl, xh, xl)
+    dw_f, db_f = hip.enc_wgrad(split, rep(dh), rep(dl), rep(xh), rep(xl))
+    torch.testing.assert_close(dw_f, dw_s * reps, rtol=2e-4, atol=2e-4 * (dw_s.abs().max().item() * reps))
+    torch.testing.assert_close(db_f, db_s * reps, rtol=2e-4, atol=2e-4 * (db_s.abs().max().item() * reps))
+    dw_again, db_again = hip.enc_wgrad(split, rep(dh), rep(dl), rep(xh), rep(xl))
+    assert torch.equal(dw_f, dw_again) and torch.equal(db_f, db_again)  # ordered slab sums: bitwise reproducible
+    if cin == 32:  # the fused front end at the same size
+        x0 = torch.randn(P0, 1, 16, 16, generator=g).cuda()
+        w1 = (torch.randn(8, 1, 5, 5, generator=g) * 0.2).cuda()
+        b1 = (torch.randn(8, generator=g) * 0.1).cuda()
+        w2 = (torch.randn(32, 8, 5, 5, generator=g) * 0.07).cuda()
+        b2 = (torch.randn(32, generator=g) * 0.1).cuda()
+        w2p = hip.enc_front_pack(w2, split)
+        o_s = hip.enc_front_fwd(split, x0, w1, b1, w2p[:2], b2)
+        o_f = hip.enc_front_fwd(split, x0.repeat(reps, 1, 1, 1).contiguous(), w1, b1, w2p[:2], b2)
+        for pl in (0, 1):
+            v = o_f[pl].view(reps, P0, 100, 32)
+            assert torch.equal(v[0], o_s[pl]) and torch.equal(v[reps - 1], o_s[pl])
+        dy0 = torch.randn(P0, 100, 32, generator=g).cuda()
+        g_s = hip.enc_front_bwd(split, x0, w1, b1, w2p[:2], b2, w2p[2:], dy0)
+        g_f = hip.enc_front_bwd(split, x0.repeat(reps, 1, 1, 1).contiguous(), w1, b1, w2p[:2], b2, w2p[2:], rep(dy0))
+        for a_, b_ in zip(g_f, g_s):
+            torch.testing.assert_close(a_, b_ * reps, rtol=2e-4, atol=2e-4 * (b_.abs().max().item() * reps))
+
+
 @pytest.mark.parametrize("cin", [1, 2])
 @pytest.mark.parametrize("split", [3, 1])
 def test_encoder_front_kernels_match_torch(hip, cin, split):
