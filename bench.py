@@ -254,7 +254,7 @@ def bench_shared(args):
     torch.manual_seed(11)
     enc = crw_encoder.CNN(False)
     net = crw_model.CRW(enc, TAU, False).cuda()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
 
     def timed(fn):
         for _ in range(max(1, args.warmup)):
@@ -398,7 +398,7 @@ def main():
     net = crw_model.CRW(enc, TAU, False).to(device)
     net.train(True)
     bucket = crw_dist.FlatGradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, foreach=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     seq = make_batch(rank, device)
     B, T, N = seq.shape[:3]
     cols_per_step = B * (T * (PATCH[1] - OVERLAP[1]) + OVERLAP[1])

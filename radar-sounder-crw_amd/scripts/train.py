@@ -76,7 +76,7 @@ def main(args):
     if args.shared_encode and not hasattr(dataset, 'columns'):
         raise SystemExit('--shared_encode needs the overlapping dataset (--dataset_full True)')
 
-    optimizer = Adam(model.parameters(), lr=args.lr)
+    optimizer = Adam(model.parameters(), lr=args.lr, fused=True)  # one kernel for all parameters (same update rule)
     bucket = crw_dist.FlatGradBucket(model.parameters())
     model.train(True)
     loss_tot, nsteps = [], 0
