@@ -414,7 +414,6 @@ struct WgradArgs {
   float *db_part;             // [nslice][COUT] fp32 partial sums
   int P, patches_per_block;
   int xcd_map;                // 1: XCD-aware id -> (slice, group) mapping (needs the slice count to be a multiple of 8)
-  int stagger;                // shader cycles by which the workgroup in the CU's second LDS slot starts late (0 = off)
   long long *stamps;          // `make STAMPS=1`: [workgroup][64]: 4 phase sums over the slice, then k-loop start times
 };
 
@@ -458,16 +457,26 @@ __device__ inline void static_for(F &&f) {
 constexpr int WG_NCO = 64, YROWS = NPIX + 1;
 
 
+// k-steps stream ACROSS patch boundaries: a patch has 100 pixels = 3 k-steps of 32 + 4, and padding every patch to
+// 4 k-steps wastes 22 % of the MFMAs and fragment reads.  Instead the last 4 (then 8) pixels of a patch are
+// deferred and contracted together with the first 28 (24) pixels of the next one; every third patch flushes
+// (4 k-steps, the last one padded): 10 k-steps per 3 patches instead of 12.  The deferred pixels lie in image
+// row 9, so all a later k-step needs of the old patch is its padded X rows 9-10 (row 11 is the zero halo) and
+// 8 dY rows: they are copied to a tail strip before the next patch overwrites the image.  Layout per plane:
+//   X : [tail strip: 24 pixels = old padded rows 9, 10][main 12x12 image]   -- the strip sits right in front of
+//       the image so that its "row 11" IS the image's (always zero) top halo row;
+//   dY: [100 pixel rows][zero row][8 tail rows = old pixels 92..99].
+constexpr int XTAIL = 2 * PAD_W, TAILPIX = 8, YROWS_ALL = YROWS + TAILPIX;
+
 template <int SPLIT, int CIN, int COUT, int NCI, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int NCO = WG_NCO, NTH = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
-  // row strides 2C + 32: with the k-slot order below the 8 pixel rows of a transposing read tile the 64 banks
-  constexpr int XS = crs<NCI>(), XPL = NPAD * XS;          // X plane: 12x12 padded image, NCI channels
-  constexpr int YS = crs<NCO>(), YPL = YROWS * YS;         // dY plane: compact rows
-  constexpr int NT = NCI / 16;                              // ci tiles of this group
-  constexpr int WCI = NT < 4 ? NT : 4, WCO = NW / WCI;     // waves along ci tiles / co tiles
-  constexpr int NCOW = NCO / 16 / WCO;                     // co tiles per wave
+  constexpr int XS = row_stride<NCI>(), XPL = (XTAIL + NPAD) * XS;  // X plane: tail strip + 12x12 padded image
+  constexpr int YS = row_stride<NCO>(), YPL = YROWS_ALL * YS;       // dY plane: compact rows + zero row + tail rows
+  constexpr int NT = NCI / 16;                                       // ci tiles of this group
+  constexpr int WCI = NT < 4 ? NT : 4, WCO = NW / WCI;              // waves along ci tiles / co tiles
+  constexpr int NCOW = NCO / 16 / WCO;                              // co tiles per wave
   static_assert(NT == WCI && COUT % NCO == 0 && CIN % NCI == 0, "tiling");
   constexpr int NGRP_CI = CIN / NCI;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -505,30 +514,127 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
   const int p_end = min(a.P, p_begin + a.patches_per_block);
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
 
-  if (a.stagger > 0) {  // second LDS slot of the CU (HW_REG_LDS_ALLOC base != 0) starts late
-    const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);
-    if ((la & 0xfffu) != 0) {
-      const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-      while ((long long)__builtin_amdgcn_s_memtime() - t0 < a.stagger) __builtin_amdgcn_s_sleep(16);
-    }
+  // zeroed once: the halo of the X images, the tail strips, and the k-padding row of the dY planes
+  for (int pl = 0; pl < NPL; ++pl) {
+    zero_halo<NCI, NTH, XS>(xs + pl * XPL + XTAIL * XS, tid);
+    for (int c = tid; c < XTAIL * XS / 16; c += NTH) *reinterpret_cast<uint4 *>(xs + pl * XPL + 16 * c) = uint4{0, 0, 0, 0};
+    for (int c = tid; c < (1 + TAILPIX) * YS / 16; c += NTH) *reinterpret_cast<uint4 *>(ys + pl * YPL + NPIX * YS + 16 * c) = uint4{0, 0, 0, 0};
   }
-  // zeroed once: the halo of the X images and the k-padding row of the dY planes
-  zero_halo<NCI, NTH, XS>(xs, tid);
-  if (SPLIT == 3) zero_halo<NCI, NTH, XS>(xs + XPL, tid);
-  if (tid < NPL * (YS / 16)) *reinterpret_cast<uint4 *>(ys + (tid / (YS / 16)) * YPL + NPIX * YS + 16 * (tid % (YS / 16))) = uint4{0, 0, 0, 0};
 
   constexpr int XCH = NCI / 8, XTOT = NPIX * XCH, XIT = (XTOT + NTH - 1) / NTH;
   constexpr int YCH = NCO / 8, YTOT = NPIX * YCH, YIT = (YTOT + NTH - 1) / NTH;
+  // tail copy: per plane XTAIL pixels x XCH chunks of X and TAILPIX rows x YCH chunks of dY
+  constexpr int TXC = XTAIL * XCH, TYC = TAILPIX * YCH, TTOT = NPL * (TXC + TYC), TIT = (TTOT + NTH - 1) / NTH;
 #ifdef CRW_CONV_STAMPS
   long long ph_[4] = {0, 0, 0, 0}, prev_ = (long long)__builtin_amdgcn_s_memtime();
 #define WG_STAMP(k) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); ph_[k] += n_ - prev_; prev_ = n_; }
 #else
 #define WG_STAMP(k)
 #endif
+
+  // LDS byte offsets (within a plane) of tail-copy chunk c: source in the image / dY rows, destination in the tails
+  auto tail_src_dst = [&](int c, int &src, int &dst) {
+    const int pl = c / (TXC + TYC), r = c % (TXC + TYC);
+    if (r < TXC) {  // X: strip pixel s <- image pixel 9*12 + s
+      const int s = r / XCH, ch = r % XCH;
+      dst = pl * XPL + s * XS + 16 * ch;
+      src = pl * XPL + (XTAIL + 9 * PAD_W + s) * XS + 16 * ch;
+    } else {        // dY: tail row j <- pixel row 92 + j   (offsets relative to xs: ys = xs + NPL * XPL)
+      const int q = r - TXC, j = q / YCH, ch = q % YCH;
+      dst = NPL * XPL + pl * YPL + (YROWS + j) * YS + 16 * ch;
+      src = NPL * XPL + pl * YPL + (NPIX - TAILPIX + j) * YS + 16 * ch;
+    }
+  };
+
+  // one k-step of 32 virtual rows: row v < carry -> deferred pixel 100 - carry + v of the previous patch (tail
+  // strips), else pixel v - carry of the current patch if it exists (and `flush` is false), else the zero row
+  const int t16 = lane & 15, q4 = t16 >> 2, pq = t16 & 3;
+  const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
+  auto row_addr = [&](int v, int carry, bool flush, uint32_t &ya, uint32_t &xa) {
+    const int i = v - carry;
+    int yrow = NPIX, xpix = XTAIL;  // zero dY row; any valid X pixel
+    if (v < carry) {
+      const int t = NPIX - carry + v;  // 92..99: image row 9, column t - 90
+      yrow = YROWS + (t - (NPIX - TAILPIX));
+      xpix = t - 90;
+    } else if (!flush && i < NPIX) {
+      yrow = i;
+      xpix = XTAIL + (i / IMG_W) * PAD_W + (i % IMG_W);  // tap (0,0) source = padded (y, x)
+    }
+    ya = ys_a + yrow * YS + lane_col + 2 * co0w;
+    xa = xs_a + xpix * XS + lane_col + 32 * wci;
+  };
+  auto kstep = [&](int ks, int carry, bool flush) {
+    // k-slot order: lane group g holds virtual rows 32 ks + 4 g + q (first read) and + 16 (second read); dY and X
+    // use the same order, so the contraction over the 32 rows is unchanged
+    uint32_t ya_lo, ya_hi, xa_lo, xa_hi;
+    row_addr(32 * ks + 4 * g + q4, carry, flush, ya_lo, xa_lo);
+    row_addr(32 * ks + 4 * g + q4 + 16, carry, flush, ya_hi, xa_hi);
+    bf8 ah[NCOW], al[NCOW];
+    static_for<NCOW>([&](auto JC) {
+      constexpr int j = decltype(JC)::value;
+      ah[j] = tr_frag<32 * j>(ya_lo, ya_hi);
+      if (SPLIT == 3) al[j] = tr_frag<YPL + 32 * j>(ya_lo, ya_hi);
+    });
+    bf8 bh[2], bl[2];
+    auto read_b = [&](auto TC) {
+      constexpr int tap = decltype(TC)::value;
+      constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * XS;  // tap shift in LDS bytes
+      bh[tap & 1] = tr_frag<XO>(xa_lo, xa_hi);
+      if (SPLIT == 3) bl[tap & 1] = tr_frag<XPL + XO>(xa_lo, xa_hi);
+    };
+    read_b(std::integral_constant<int, 0>{});
+    static_for<9>([&](auto TC) {
+      constexpr int tap = decltype(TC)::value;
+      if constexpr (tap < 8) {
+        read_b(std::integral_constant<int, tap + 1>{});
+        // LDS returns in order: all but the reads just issued (2 ds_read per fragment) have landed
+        if (SPLIT == 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (tap == 0) {
+        if (bias_wave) {
+          const s8v o = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};  // bf16 1.0
+          const bf8 ones = __builtin_bit_cast(bf8, o);
+#pragma unroll
+          for (int j = 0; j < NCOW; ++j) {
+            if (SPLIT == 3) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], ones, accb[j], 0, 0, 0);
+            accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], ones, accb[j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NCOW; ++j) {
+        if (SPLIT == 3) {
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl[tap & 1], acc[tap][j], 0, 0, 0);
+        }
+        acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
+      }
+    });
+  };
+
+  int carry = 0;  // deferred pixels of the previous patch waiting in the tail strips (0, 4 or 8)
+  uint4 tv[TIT];
+#pragma unroll
+  for (int i = 0; i < TIT; ++i) tv[i] = uint4{0, 0, 0, 0};
   for (int p = p_begin; p < p_end; ++p) {
-    __syncthreads();  // previous patch fully consumed
+    __syncthreads();  // previous patch fully consumed (its tail rows are in tv[])
     WG_STAMP(3)
     {
+      // the deferred rows of the previous patch -> tail strips (read into tv[] before the barrier above)
+#pragma unroll
+      for (int i = 0; i < TIT; ++i) {
+        const int c = tid + i * NTH;
+        if (TTOT % NTH == 0 || c < TTOT) {
+          int src, dst;
+          tail_src_dst(c, src, dst);
+          *reinterpret_cast<uint4 *>(xs + dst) = tv[i];
+        }
+      }
       // all global loads of the patch are issued before the first LDS store (one round trip)
       uint4 xv[NPL][XIT], yv[NPL][YIT];
 #pragma unroll
@@ -556,7 +662,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
         for (int i = 0; i < XIT; ++i) {
           const int c = tid + i * NTH;
           if (XTOT % NTH == 0 || c < XTOT)
-            *reinterpret_cast<uint4 *>(xs + pl * XPL + interior_pp(c / XCH) * XS + 16 * (c % XCH)) = xv[pl][i];
+            *reinterpret_cast<uint4 *>(xs + pl * XPL + (XTAIL + interior_pp(c / XCH)) * XS + 16 * (c % XCH)) = xv[pl][i];
         }
       if (a.dgap) {
         // dY[i][c] = dgap[c] / 100 where the forward activation (hi plane, in yv[0]) is non-zero
@@ -601,71 +707,35 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
     if (a.stamps && tid == 0 && p - p_begin < 60)  // absolute k-loop start times of the first patches (phase drift study)
       a.stamps[(long)blockIdx.x * 64 + 4 + (p - p_begin)] = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    // reduction over the 100 interior pixels (k = interior index i, 4 k-steps of 32; rows i >= 100 read the
-    // zero row of dY, so they add nothing; their X row is pixel 0 so that every tap shift stays inside the
-    // plane).  X pixel for dY pixel i and tap (dy,dx): interior_pp(i) + (dy-1)*12 + (dx-1).
-    constexpr int KSTEPS = (NPIX + 31) / 32;
-    const int t16 = lane & 15, q = t16 >> 2, pq = t16 & 3;
-    const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
+    // carry 0: pixels 0..95 now, 4 deferred; carry 4: 4 old + pixels 0..91, 8 deferred; carry 8: 8 old + all 100
+    // pixels (4 k-steps, the last one padded with the zero row), nothing deferred
+    const int nks = carry == 8 ? 4 : 3;
 #pragma unroll 1
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      // k-slot order: lane group g holds pixels 32 ks + 4 g + q (first read) and + 16 (second read), so the 32 lanes
-      // of one ds_read_b64_tr_b16 bank group touch 8 CONSECUTIVE pixel rows (conflict-free on the 2C+32 stride);
-      // dY and X use the same order, so the contraction over the 32 pixels is unchanged
-      const int i_lo = 32 * ks + 4 * g + q, i_hi = i_lo + 16;
-      const int px_lo = i_lo < NPIX ? interior_pp(i_lo) - PAD_W - 1 : 0;  // tap (dy, dx) = (0, 0)
-      const int px_hi = i_hi < NPIX ? interior_pp(i_hi) - PAD_W - 1 : 0;
-      const uint32_t ya_lo = ys_a + min(i_lo, NPIX) * YS + lane_col + 2 * co0w;
-      const uint32_t ya_hi = ys_a + min(i_hi, NPIX) * YS + lane_col + 2 * co0w;
-      const uint32_t xa_lo = xs_a + px_lo * XS + lane_col + 32 * wci;
-      const uint32_t xa_hi = xs_a + px_hi * XS + lane_col + 32 * wci;
-      bf8 ah[NCOW], al[NCOW];
-      static_for<NCOW>([&](auto JC) {
-        constexpr int j = decltype(JC)::value;
-        ah[j] = tr_frag<32 * j>(ya_lo, ya_hi);
-        if (SPLIT == 3) al[j] = tr_frag<YPL + 32 * j>(ya_lo, ya_hi);
-      });
-      bf8 bh[2], bl[2];
-      auto read_b = [&](auto TC) {
-        constexpr int tap = decltype(TC)::value;
-        constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * XS;  // tap shift in LDS bytes
-        bh[tap & 1] = tr_frag<XO>(xa_lo, xa_hi);
-        if (SPLIT == 3) bl[tap & 1] = tr_frag<XPL + XO>(xa_lo, xa_hi);
-      };
-      read_b(std::integral_constant<int, 0>{});
-      static_for<9>([&](auto TC) {
-        constexpr int tap = decltype(TC)::value;
-        if constexpr (tap < 8) {
-          read_b(std::integral_constant<int, tap + 1>{});
-          // LDS returns in order: all but the reads just issued (2 ds_read per fragment) have landed
-          if (SPLIT == 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (tap == 0) {
-          if (bias_wave) {
-            const s8v o = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};  // bf16 1.0
-            const bf8 ones = __builtin_bit_cast(bf8, o);
+    for (int ks = 0; ks < nks; ++ks) kstep(ks, carry, false);
+    carry = carry == 8 ? 0 : carry + 4;
+    // this thread's share of the rows a later k-step still needs (image rows 9-10, dY rows 92..99)
 #pragma unroll
-            for (int j = 0; j < NCOW; ++j) {
-              if (SPLIT == 3) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], ones, accb[j], 0, 0, 0);
-              accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], ones, accb[j], 0, 0, 0);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NCOW; ++j) {
-          if (SPLIT == 3) {
-            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
-            acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl[tap & 1], acc[tap][j], 0, 0, 0);
-          }
-          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
-        }
-      });
+    for (int i = 0; i < TIT; ++i) {
+      const int c = min(tid + i * NTH, TTOT - 1);
+      int src, dst;
+      tail_src_dst(c, src, dst);
+      tv[i] = *reinterpret_cast<const uint4 *>(xs + src);
     }
     WG_STAMP(2)
+  }
+  if (carry > 0) {  // the slice ended with deferred pixels: one more k-step over the tail strips alone
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+      const int c = tid + i * NTH;
+      if (TTOT % NTH == 0 || c < TTOT) {
+        int src, dst;
+        tail_src_dst(c, src, dst);
+        *reinterpret_cast<uint4 *>(xs + dst) = tv[i];
+      }
+    }
+    __syncthreads();
+    kstep(0, carry, true);
   }
 #ifdef CRW_CONV_STAMPS
   if (a.stamps && tid == 0)
@@ -833,7 +903,7 @@ int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
   // measured (tools/probe_conv.py): hi/lo pairs are faster with 4 waves (144 accumulator registers per wave, 26
   // fragment reads per 108 MFMAs), plain bf16 with 8 (4 waves per SIMD hide the load phase)
   constexpr int NCI = wgrad_nci(CIN), NW = SPLIT == 3 ? 4 : 8;
-  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * (NPAD * crs<NCI>() + YROWS * crs<WG_NCO>());
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * ((XTAIL + NPAD) * row_stride<NCI>() + YROWS_ALL * row_stride<WG_NCO>());
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI, NW>,
@@ -859,13 +929,6 @@ inline int ew_grid(long n) {
 using namespace crw;
 
 long long *g_conv_stamps = nullptr;  // set by crw_debug_conv_stamps (diagnostics)
-
-static int wgrad_stagger() {
-#ifdef CRW_CONV_STAMPS
-  if (const char *e = getenv("CRW_STAGGER")) return atoi(e);
-#endif
-  return 0;
-}
 
 extern "C" {
 
@@ -950,7 +1013,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   const int nslice = wgrad_slices(P, cin, cout, split);
   const int ppb = (P + nslice - 1) / nslice;
   float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
-  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, nslice % 8 == 0 ? 1 : 0, wgrad_stagger(), g_conv_stamps};
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, nslice % 8 == 0 ? 1 : 0, g_conv_stamps};
   int st = CRW_EINVAL;
 #define CRW_WG_CASE(CI, CO)                                                                  \
   if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);
