@@ -6,22 +6,26 @@
 // them one by one is pure launch latency (~7 us each, 2 x 29 per step).  Here ONE workgroup per
 // (batch item, chain) walks all T-3 steps: the running matrix stays in LDS (double buffered),
 // P_{k+1} is prefetched into registers while step k's MFMAs (v_mfma_f32_16x16x4_f32, exact fp32)
-// run, one barrier per step.  Results are written to HBM each step because the backward pass and
+// run, one (LDS-only) barrier per step.  Results are written to HBM each step because the backward pass and
 // the batched cycle products At_k = Lt_k^T R_k need every Lt_k / R_k.
 #include "crw_common.h"
 
 namespace crw {
 namespace {
 
-template <int NP, bool BWD>
-__global__ __launch_bounds__(256) void chain_small_kernel(const float *__restrict__ Gt, const float *__restrict__ F,
+template <int NP, bool BWD, int NTH>
+__global__ __launch_bounds__(NTH) void chain_small_kernel(const float *__restrict__ Gt, const float *__restrict__ F,
                                                           float *__restrict__ X0, float *__restrict__ X1, int B,
                                                           int K) {
-  constexpr int LD = NP + 16;          // (LD mod 32) == 16: conflict-free ds_read_b32 fragment reads
+  constexpr int LD = NP + 16;          // (LD mod 32) == 16: conflict-free ds_read_b32 fragment reads (k-major images)
+  constexpr int LDA = BWD ? LD : NP + 4;  // forward keeps P row-major (m-major): rows 4 banks apart, 2-way at worst,
+                                          // and no transposing 4-byte scatter (16-way bank conflicts) when staging P
   constexpr int NT = NP / 16;          // 16x16 tiles per side
-  constexpr int TPW = NT * NT / 4;     // tiles per wave (4 or 1)
-  constexpr int V4 = NP * NP / 4 / 256;  // float4 per thread per matrix
-  __shared__ __attribute__((aligned(16))) float As[2][NP * LD];
+  constexpr int TPW = NT * NT / (NTH / 64);  // tiles per wave: 1 (the chain is sequential and MFMA-issue bound per
+                                              // wave, so Np = 64 runs 16 waves with one tile each)
+  constexpr int V4 = NP * NP / 4 / NTH;      // float4 per thread per matrix
+  static_assert(TPW >= 1 && V4 >= 1, "threads");
+  __shared__ __attribute__((aligned(16))) float As[2][NP * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][NP * LD];
 
   const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
@@ -31,24 +35,28 @@ __global__ __launch_bounds__(256) void chain_small_kernel(const float *__restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto mat = [&](const float *base, int i) { return base + (long)i * BM + (long)b * M; };
 
+  // backward only: the k-local terms Y_out that seed the accumulators, fetched one step ahead like P
+  float yreg[TPW][4];
+  auto load_Y = [&](int i) {
+    const float *y = mat(X, i);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave * TPW + t, r0 = (tile / NT) * 16, c0 = (tile % NT) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yreg[t][r] = y[(long)(r0 + (lane >> 4) * 4 + r) * NP + c0 + (lane & 15)];
+    }
+  };
   float4 preg[V4];
   auto load_P = [&](int i) {
     const float *src = mat(P, i);
 #pragma unroll
-    for (int v = 0; v < V4; ++v) preg[v] = *reinterpret_cast<const float4 *>(src + 4 * (tid + v * 256));
+    for (int v = 0; v < V4; ++v) preg[v] = *reinterpret_cast<const float4 *>(src + 4 * (tid + v * NTH));
   };
-  auto store_P = [&](float *as) {  // As[k][m] = op(P)(m,k)
+  auto store_P = [&](float *as) {  // backward: As[k][m] = P^T(m,k) = P[k][m]; forward: As[m][k] = P[m][k] -- both row copies
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const int e = 4 * (tid + v * 256), r = e / NP, c = e % NP;  // P[r][c..c+3]
-      if (BWD) {  // op(P) = P^T: (m,k) = P[k][m] -> As[k = r][m = c..]
-        *reinterpret_cast<float4 *>(as + r * LD + c) = preg[v];
-      } else {    // (m,k) = P[m][k] -> As[k = c..][m = r]
-        as[(c + 0) * LD + r] = preg[v].x;
-        as[(c + 1) * LD + r] = preg[v].y;
-        as[(c + 2) * LD + r] = preg[v].z;
-        as[(c + 3) * LD + r] = preg[v].w;
-      }
+      const int e = 4 * (tid + v * NTH), r = e / NP, c = e % NP;  // P[r][c..c+3]
+      *reinterpret_cast<float4 *>(as + r * LDA + c) = preg[v];
     }
   };
 
@@ -60,11 +68,12 @@ __global__ __launch_bounds__(256) void chain_small_kernel(const float *__restric
     const float *src = mat(X, first_in);
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const int e = 4 * (tid + v * 256), r = e / NP, c = e % NP;
+      const int e = 4 * (tid + v * NTH), r = e / NP, c = e % NP;
       *reinterpret_cast<float4 *>(&Bs[0][r * LD + c]) = *reinterpret_cast<const float4 *>(src + e);
     }
     load_P(BWD ? K - 1 : 1);
     store_P(As[0]);
+    if (BWD) load_Y(K - 2);
   }
   __syncthreads();
 
@@ -83,22 +92,22 @@ __global__ __launch_bounds__(256) void chain_small_kernel(const float *__restric
       tr[t] = (tile / NT) * 16;
       tc[t] = (tile % NT) * 16;
       if (BWD) {
-        const float *y = mat(X, out);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = y[(long)(tr[t] + (lane >> 4) * 4 + r) * NP + tc[t] + (lane & 15)];
+        for (int r = 0; r < 4; ++r) acc[t][r] = yreg[t][r];
       } else {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if (BWD && more) load_Y(out - 1);  // next step's seed (written by earlier kernels, never by this one)
     const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll 4
     for (int kk = 0; kk < NP; kk += 4) {
       const int kr = kk + (lane >> 4), c = lane & 15;
       // TPW == 4: the wave's tiles share one row block (tile / NT == wave)
-      const float a0 = as[kr * LD + tr[0] + c];
+      const float a0 = BWD ? as[kr * LDA + tr[0] + c] : as[(tr[0] + c) * LDA + kr];
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const float a = (TPW == 4) ? a0 : as[kr * LD + tr[t] + c];
+        const float a = (TPW == 4) ? a0 : (BWD ? as[kr * LDA + tr[t] + c] : as[(tr[t] + c) * LDA + kr]);
         const float bv = bs[kr * LD + tc[t] + c];
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
       }
@@ -114,7 +123,10 @@ __global__ __launch_bounds__(256) void chain_small_kernel(const float *__restric
         bn[row * LD + col] = acc[t][r];
       }
     if (more) store_P(As[cur ^ 1]);
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for this step's result stores and for the
+    // prefetch of the next P, i.e. one HBM round trip per step of a 29-step sequential chain.  Nothing written to
+    // global memory in this kernel is read back by another lane.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     cur ^= 1;
   }
 }
@@ -123,9 +135,9 @@ template <bool BWD>
 int launch(const float *Gt, const float *F, float *X0, float *X1, int B, int K, int n, hipStream_t s) {
   if (B < 1 || K < 1 || (n != 32 && n != 64)) return CRW_EINVAL;
   if (n == 64)
-    hipLaunchKernelGGL((chain_small_kernel<64, BWD>), dim3(2 * B), dim3(256), 0, s, Gt, F, X0, X1, B, K);
+    hipLaunchKernelGGL((chain_small_kernel<64, BWD, 1024>), dim3(2 * B), dim3(1024), 0, s, Gt, F, X0, X1, B, K);
   else
-    hipLaunchKernelGGL((chain_small_kernel<32, BWD>), dim3(2 * B), dim3(256), 0, s, Gt, F, X0, X1, B, K);
+    hipLaunchKernelGGL((chain_small_kernel<32, BWD, 256>), dim3(2 * B), dim3(256), 0, s, Gt, F, X0, X1, B, K);
   return check_launch();
 }
 
