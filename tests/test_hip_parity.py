@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI / ctypes) against the golden vectors of the
 reference and against the CPU oracle on seeded inputs.  Tolerance: north_star asks for 1e-4 fp32
 on the loss and propagated label map; label maps are compared exactly."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -171,6 +173,34 @@ def test_full_model_matches_reference(hip, name, wname, convs):
         ref = g["grad." + k]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max())
     assert crw_model.CRW(enc, 0.01, bool(g["pos_embed"]), only_a=True).cuda()(dev(g["seq"])).shape == A.shape
+
+
+def test_full_model_at_baseline_shape_vs_oracle(hip):
+    """One item of BASELINE configs[2] ([T,N] = [32,63], 16x16 patches, 2016 patches through the whole HIP conv
+    trunk + affinity + walk) against the CPU oracle: loss within 1e-4 relative (the north_star tolerance), every
+    parameter gradient within 2 % of its scale and > 0.9999 cosine."""
+    import model as crw_model
+    import encoder as crw_encoder
+    import dataset as crw_dataset
+    from oracle import crw_oracle as orc
+    ds = crw_dataset.RGDataset.synthetic(512, 1024, 32, (16, 16), (8, 0), seed=11)
+    item = ds[1][None].contiguous()  # [1, 32, 63, 16, 16]
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    loss_ref, _, _ = orc.crw_forward_torch(item, sd, 0.01)
+    loss_ref.backward()
+    net = crw_model.CRW(enc, 0.01, False).cuda()
+    loss, A = net(item.cuda())
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    loss.backward()
+    for k, p in enc.named_parameters():
+        r = sd[k].grad.double().flatten()
+        gq = p.grad.cpu().double().flatten()
+        cos = torch.dot(r, gq) / (r.norm() * gq.norm() + 1e-300)
+        assert cos > 0.9999, (k, cos.item())
+        assert (gq - r).abs().max() <= 2e-2 * r.abs().max(), k
 
 
 @pytest.mark.parametrize("stride", [1, 2])
