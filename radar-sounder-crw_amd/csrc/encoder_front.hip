@@ -355,11 +355,18 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   constexpr int DYIT = (ON * 32 / 4 + NTH - 1) / NTH;  // float4 chunks of dy per thread (800 chunks)
   float4 dy_r[DYIT];
   float x_r = 0.f;                                      // cin*256 <= 512 floats: threads < cin*256 hold one each
+  // buffer loads: base in a scalar resource descriptor, a 32-bit per-lane offset and a scalar per-patch offset --
+  // no 64-bit per-lane pointers live across the patch loop (they were being spilled and reloaded every
+  // iteration with a full vmcnt(0) wait); reads past the end of the tensors return 0
+  const __amdgpu_buffer_rsrc_t dy_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)((long)a.f.P * ON * 32 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)a.f.x, 0, (int)((long)a.f.P * cin * 256 * 4), 0x00020000);
   auto fetch = [&](int pt) {
-    const float4 *dsrc = reinterpret_cast<const float4 *>(a.dy + (long)pt * ON * 32);
 #pragma unroll
-    for (int i = 0; i < DYIT; ++i) dy_r[i] = dsrc[min(tid + i * NTH, ON * 32 / 4 - 1)];
-    x_r = a.f.x[(long)pt * cin * 256 + min(tid, cin * 256 - 1)];
+    for (int i = 0; i < DYIT; ++i)
+      dy_r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dy_rs, (tid + i * NTH) * 16, pt * (ON * 32 * 4), 0));
+    x_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, tid * 4, pt * (cin * 256 * 4), 0));
   };
   if (p_begin < p_end) fetch(p_begin);
   for (int pt = p_begin; pt < p_end; ++pt) {
