@@ -454,7 +454,9 @@ def main():
                 for cin, cout in ((128, 128), (64, 128), (32, 64)):
                     alg = 2.0 * P * 100 * cin * cout * 9  # algorithmic flops of one pass over one layer
                     for kname, kms in conv_probe(P, cin, cout, split).items():
-                        pad = 128.0 / 100.0 if "wgrad" in kname else 112.0 / 100.0  # MFMA tile padding of the pixel dim
+                        pad = (10 * 32 / 3) / 100.0 if "wgrad" in kname else 112.0 / 100.0  # MFMA padding of the pixel dim: the weight
+                        # gradient streams k-steps across patches (10 k-steps of 32 pixels per 3 patches), forward / backward-data
+                        # run 7 row tiles of 16 per patch
                         kernels.append({"kernel": f"{kname} cin={cin} cout={cout}", "bound": "mfma",
                                         "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
                                         "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
