@@ -122,6 +122,9 @@ int crw_enc_pack_weights(const float *w, int cout, int cin, uint16_t *fwd_hi, ui
                          uint16_t *bwd_hi, uint16_t *bwd_lo, crw_stream_t stream);
 /* fp32 NCHW [P][C][10][10] (output of pool2) -> planes */
 int crw_enc_pack_input(const float *x, int P, int C, uint16_t *x_hi, uint16_t *x_lo, crw_stream_t stream);
+/* same for feature maps of any size: fp32 NCHW [P][C][H][W] -> planes [P][H*W][C] */
+int crw_enc_pack_input_map(const float *x, int P, int C, int H, int W, uint16_t *x_hi, uint16_t *x_lo,
+                           crw_stream_t stream);
 /* mode 0: y = relu(conv3x3(x, w) + bias), optional gap[P][cout] = mean over pixels (AdaptiveAvgPool2d(1));
  * mode 1: backward-data, y = conv3x3(x = dY, w = backward planes), zeroed where mask_hi (the forward
  *         activation of the layer below, [P][100][cout]) is 0; bias ignored.
@@ -134,6 +137,13 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
                     const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi,
                     uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, const float *dgap,
                     crw_stream_t stream);
+/* Forward conv + bias + ReLU on feature maps of ANY size (patch sizes other than 16x16; src/encoder.py:49-53 is
+ * size-agnostic): planes are [P][H][W][C]; a workgroup computes one 10x10 output tile.  y_hi/y_lo may be NULL
+ * when only the pooled result is wanted; gap_part [P * ceil(H/10) * ceil(W/10)][cout] receives per-tile SUMS
+ * over the in-map pixels (the caller adds the tiles and divides by H*W = AdaptiveAvgPool2d(1)). */
+int crw_enc_conv3x3_map(int split, int P, int H, int W, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
+                        const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, uint16_t *y_hi, uint16_t *y_lo,
+                        float *gap_part, crw_stream_t stream);
 /* dY planes [P][100][C] = dgap[P][C] / 100 where y_hi != 0 (backward of ReLU + global average pool) */
 int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
                     crw_stream_t stream);

@@ -38,6 +38,8 @@ SIGNATURES = {
     "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
     "crw_enc_pack_weights": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
+    "crw_enc_pack_input_map": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_enc_conv3x3_map": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_conv3x3": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p]),
     "crw_enc_wgrad_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
@@ -242,6 +244,31 @@ def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=
                                  _bf(yl, "yl"), _dev(yf, "yf") if f32 else None, _dev(gp, "gap") if gap else None,
                                  _dev(dgap, "dgap") if dgap is not None else None, _stream()), "crw_enc_conv3x3")
     return yh, yl, yf, gp
+
+
+def enc_pack_input_map(x, split):
+    """fp32 NCHW [P,C,H,W] -> bf16 planes [P, H*W, C] (hi, lo | None)."""
+    P, C, H, W = x.shape
+    xh = torch.empty(P, H * W, C, dtype=_BF, device=x.device)
+    xl = torch.empty_like(xh) if split == 3 else None
+    _check(lib().crw_enc_pack_input_map(_dev(x.contiguous(), "x"), P, C, H, W, _bf(xh, "xh"), _bf(xl, "xl"), _stream()),
+           "crw_enc_pack_input_map")
+    return xh, xl
+
+
+def enc_conv3x3_map(split, xh, xl, wh, wl, cout, H, W, bias=None, planes=True, gap=False, lo_plane=True):
+    """relu(conv3x3 + bias) on feature maps [P, H*W, cin] of any size -> (yh, yl, gap [P, cout] mean | None)."""
+    P, hw, cin = xh.shape
+    assert hw == H * W
+    dev = xh.device
+    yh = torch.empty(P, hw, cout, dtype=_BF, device=dev) if planes else None
+    yl = torch.empty_like(yh) if (planes and split == 3 and lo_plane) else None
+    ntile = ((H + 9) // 10) * ((W + 9) // 10)
+    gp = torch.empty(P, ntile, cout, dtype=torch.float32, device=dev) if gap else None
+    _check(lib().crw_enc_conv3x3_map(split, P, H, W, cin, cout, _bf(xh, "xh"), _bf(xl, "xl"), _bf(wh, "wh"), _bf(wl, "wl"),
+                                     _dev(bias, "bias") if bias is not None else None, _bf(yh, "yh"), _bf(yl, "yl"),
+                                     _dev(gp, "gap") if gap else None, _stream()), "crw_enc_conv3x3_map")
+    return yh, yl, (gp.sum(1) / float(hw) if gap else None)
 
 
 def enc_gap_bwd(dgap, yh, split):

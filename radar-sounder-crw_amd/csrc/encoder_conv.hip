@@ -165,6 +165,8 @@ struct ConvArgs {
                              // activation hi plane) instead of being read from xh/xl
   int P;
   long long *stamps;         // diagnostic builds only: [grid][5] s_memtime at phase boundaries (else null)
+  // MAP variant only: planes are feature maps [P][mh][mw][C] of any size, a workgroup computes one 10x10 output tile
+  int mh, mw, tiles_x, tiles_y;
 };
 
 // One workgroup = one patch, NW waves (4 or 8).  With 8 waves a wave owns one 16-channel output tile
@@ -172,13 +174,19 @@ struct ConvArgs {
 // load / epilogue phases are then covered by the other workgroup's MFMAs, and twice as many waves keep
 // weight-fragment loads in flight (4-wave workgroups at 2 waves per SIMD measured ~65 % matrix-pipe
 // occupancy: each workgroup's phases are latency-bound on their own).
-template <int SPLIT, int CIN, int COUT, int MODE, int NW>
+// MAP = true: the same kernel on feature maps of any size (other patch sizes than 16x16, e.g. the 26x26 maps of
+// 32x32 patches): workgroup = (patch, 10x10 output tile); the 12x12 input window is gathered from the map with
+// zeros outside it, only in-map output pixels are stored, `gap` receives per-tile SUMS (forward only).
+template <int SPLIT, int CIN, int COUT, int MODE, int NW, bool MAP = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   constexpr int PPW = 1, NT = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
-  constexpr int RSI = crs<CIN>(), RSO = crs<COUT>();  // LDS row strides of the input image / the output staging
-  constexpr int PLANE = PLANE_ROWS * crs<CMAX>();     // byte offset of the lo plane
+  // LDS row strides of the input image / the output staging and byte offset of the lo plane.  MAP windows carry real
+  // neighbour data in their halo rows, so the two planes cannot share a halo row: full 144-row planes on the
+  // 2C+16 stride (2-way conflicts, still two workgroups per CU)
+  constexpr int RSI = MAP ? row_stride<CIN>() : crs<CIN>(), RSO = MAP ? row_stride<COUT>() : crs<COUT>();
+  constexpr int PLANE = MAP ? NPAD * row_stride<CMAX>() : PLANE_ROWS * crs<CMAX>();
   constexpr int WN = (COUT / 16 >= NW) ? NW : COUT / 16;  // waves across the output channels
   constexpr int WM = NW / WN;                             // waves across the pixel row tiles
   constexpr int NTW = COUT / 16 / WN;                     // 16-wide column tiles per wave
@@ -186,7 +194,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   constexpr int KCH = CIN / 32;                           // 32-deep k-steps per tap
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
-  const int p0 = blockIdx.x;
+  int p0 = blockIdx.x, ty0 = 0, tx0 = 0;  // patch; MAP: origin of this workgroup's output tile in the map
+  if constexpr (MAP) {
+    const int ntile = a.tiles_x * a.tiles_y, tile = blockIdx.x % ntile;
+    p0 = blockIdx.x / ntile;
+    ty0 = (tile / a.tiles_x) * IMG_W;
+    tx0 = (tile % a.tiles_x) * IMG_W;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
 
@@ -199,7 +213,29 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   };
   stamp(0);
   // ---- patch -> LDS ------------------------------------------------------------------------------
-  {
+  if constexpr (MAP) {
+    // all 144 pixels of the 12x12 window (halo included) come from the map; outside it they are zero
+    constexpr int NCH = CIN / 8, WTOT = NPAD * NCH, WIT = (WTOT + NT - 1) / NT;
+    uint4 vh[WIT], vl[WIT];
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const int c = min(tid + i * NT, WTOT - 1), wp = c / NCH, ch = c % NCH;
+      const int my = ty0 + wp / PAD_W - 1, mx = tx0 + wp % PAD_W - 1;
+      const bool ok = my >= 0 && my < a.mh && mx >= 0 && mx < a.mw;
+      const long off = (((long)p0 * a.mh + min(max(my, 0), a.mh - 1)) * a.mw + min(max(mx, 0), a.mw - 1)) * CIN + 8 * ch;
+      vh[i] = *reinterpret_cast<const uint4 *>(a.xh + off);  // unconditional, clamped (see PlaneLoad)
+      if (SPLIT == 3) vl[i] = *reinterpret_cast<const uint4 *>(a.xl + off);
+      if (!ok) vh[i] = vl[i] = uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const int c = tid + i * NT;
+      if (WTOT % NT == 0 || c < WTOT) {
+        *reinterpret_cast<uint4 *>(lds + (c / NCH) * RSI + 16 * (c % NCH)) = vh[i];
+        if (SPLIT == 3) *reinterpret_cast<uint4 *>(lds + PLANE + (c / NCH) * RSI + 16 * (c % NCH)) = vl[i];
+      }
+    }
+  } else {
     const int p = p0;
     char *img = lds;
     zero_halo<CIN, NT, RSI>(img, tid);
@@ -353,9 +389,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
             float v = acc[0][k][j][r];
             if (MODE == 0) {
               v = fmaxf(v + bias_r[j], 0.f);
-              gsum[j] += v;
+              if (!MAP || (ty0 + i / IMG_W < a.mh && tx0 + i % IMG_W < a.mw)) gsum[j] += v;
             }
-            if (a.yf) a.yf[((long)p * NPIX + i) * COUT + co] = v;
+            if (!MAP && a.yf) a.yf[((long)p * NPIX + i) * COUT + co] = v;
             if (a.yh) {
               const uint16_t h = f2bf(v);
               *reinterpret_cast<uint16_t *>(img + pp * RSO + 2 * co) = h;
@@ -370,7 +406,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
         float s = gsum[j];
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0) a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
+        if (g == 0) {
+          if constexpr (MAP) a.gap[(long)blockIdx.x * COUT + co_w + 16 * j + r16] = s;  // per-tile sum; the caller reduces
+          else a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
+        }
       }
     }
   }
@@ -391,12 +430,19 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
     }
     for (int pl = 0; pl < NPL; ++pl) {
       if (pl && !a.yl) break;  // the lo plane is optional (nobody reads conv5's)
-      uint16_t *dst = (pl ? a.yl : a.yh) + (long)p * NPIX * COUT;
+      uint16_t *dst = (pl ? a.yl : a.yh) + (MAP ? 0 : (long)p * NPIX * COUT);
       const char *src = lds + pl * PLANE;
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int c = tid + it * NT;
-        if (c < TOTAL) {
+        bool in_map = true;
+        long dpix = c / NCH;  // destination pixel index (in the patch plane, or in the whole map tensor)
+        if constexpr (MAP) {
+          const int oy = ty0 + (c / NCH) / IMG_W, ox = tx0 + (c / NCH) % IMG_W;
+          in_map = oy < a.mh && ox < a.mw;
+          dpix = ((long)p * a.mh + oy) * a.mw + ox;
+        }
+        if (c < TOTAL && in_map) {
           uint4 v = *reinterpret_cast<const uint4 *>(src + interior_pp(c / NCH) * RSO + 16 * (c % NCH));
           if (mk) {  // keep a bf16 lane only where the mask lane is non-zero
             const uint32_t m[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
@@ -408,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
             }
             v = uint4{o[0], o[1], o[2], o[3]};
           }
-          *reinterpret_cast<uint4 *>(dst + (long)c * 8) = v;
+          *reinterpret_cast<uint4 *>(dst + dpix * COUT + 8 * (c % NCH)) = v;
         }
       }
     }
@@ -861,13 +907,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
 }
 
 // fp32 NCHW [P][C][10][10] -> channels-last planes [P][100][C]
-__global__ __launch_bounds__(256) void pack_input_kernel(const float *__restrict__ x, int P, int C, uint16_t *xh,
+__global__ __launch_bounds__(256) void pack_input_kernel(const float *__restrict__ x, int P, int C, int npix, uint16_t *xh,
                                                          uint16_t *xl) {
-  const long n = (long)P * NPIX * C;
+  const long n = (long)P * npix * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-    const int c = e % C, i = (e / C) % NPIX;
-    const long p = e / ((long)C * NPIX);
-    const float v = x[(p * C + c) * NPIX + i];
+    const int c = e % C, i = (e / C) % npix;
+    const long p = e / ((long)C * npix);
+    const float v = x[(p * C + c) * npix + i];
     const uint16_t h = f2bf(v);
     xh[e] = h;
     if (xl) xl[e] = f2bf(v - bf2f(h));
@@ -910,6 +956,23 @@ int launch_conv_nw(const ConvArgs &a, hipStream_t s) {
     attr = true;
   }
   hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW>), dim3(a.P), dim3(NW * 64), lds, s, a);
+  return check_launch();
+}
+
+template <int SPLIT, int CIN, int COUT>
+int launch_conv_map(const ConvArgs &a, hipStream_t s) {
+  constexpr int CMAX = CIN > COUT ? CIN : COUT, NW = (SPLIT == 3 ? 8 : 4);
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * NPAD * row_stride<CMAX>();
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, 0, NW, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, 0, NW, true>), dim3(a.P * a.tiles_x * a.tiles_y), dim3(NW * 64), lds, s, a);
   return check_launch();
 }
 
@@ -974,8 +1037,36 @@ int crw_enc_pack_input(const float *x, int P, int C, uint16_t *xh, uint16_t *xl,
   clear_stale_error();
   if (!x || !xh || P < 1 || C < 8 || C % 8) return CRW_EINVAL;
   hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((long)P * NPIX * C)), dim3(256), 0, (hipStream_t)stream, x, P, C,
-                     xh, xl);
+                     NPIX, xh, xl);
   return check_launch();
+}
+
+int crw_enc_pack_input_map(const float *x, int P, int C, int H, int W, uint16_t *xh, uint16_t *xl, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !xh || P < 1 || C < 8 || C % 8 || H < 1 || W < 1) return CRW_EINVAL;
+  hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((long)P * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, P, C,
+                     H * W, xh, xl);
+  return check_launch();
+}
+
+int crw_enc_conv3x3_map(int split, int P, int H, int W, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
+                        const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, uint16_t *y_hi, uint16_t *y_lo,
+                        float *gap_part, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x_hi || !w_hi || P < 1 || H < 1 || W < 1 || (split != 1 && split != 3)) return CRW_EINVAL;
+  if (split == 3 && (!w_lo || !x_lo)) return CRW_EINVAL;
+  if (!y_hi && !gap_part) return CRW_EINVAL;
+  const int tx = (W + IMG_W - 1) / IMG_W, ty = (H + IMG_W - 1) / IMG_W;
+  if ((long)P * tx * ty > 0x7fffffffL) return CRW_EINVAL;
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, nullptr, y_hi, y_lo, nullptr, gap_part, nullptr, P, nullptr, H, W, tx, ty};
+  hipStream_t s = (hipStream_t)stream;
+#define CRW_MAP_CASE(CI, CO) \
+  if (cin == CI && cout == CO) return split == 3 ? launch_conv_map<3, CI, CO>(a, s) : launch_conv_map<1, CI, CO>(a, s);
+  CRW_MAP_CASE(32, 64)
+  CRW_MAP_CASE(64, 128)
+  CRW_MAP_CASE(128, 128)
+#undef CRW_MAP_CASE
+  return CRW_EINVAL;
 }
 
 int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
@@ -995,7 +1086,7 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
   if (split == 3 && (!w_lo || (!x_lo && !dgap))) return CRW_EINVAL;
   if (dgap && mode != 1) return CRW_EINVAL;
   if (!y_hi && !y_f32 && !gap) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, g_conv_stamps};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap, dgap, P, g_conv_stamps, 0, 0, 1, 1};
   hipStream_t s = (hipStream_t)stream;
 #define CRW_CONV_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \

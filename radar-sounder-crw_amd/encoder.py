@@ -8,7 +8,8 @@ conv1-ReLU-pool-conv2-ReLU-pool (csrc/encoder_front.hip), the 3x3 layers conv3/c
 and the global average pool (csrc/encoder_conv.hip), forward AND backward -- runs in hand-written
 HIP kernels (``CNN.hip_convs``: "bf16x3" = hi/lo bf16 operand pairs on the matrix cores, fp32-grade
 results, the default; "bf16" = plain bf16 operands; None = PyTorch-ROCm ops).  Only the linear
-head stays a PyTorch op.  Other patch sizes, CPU tensors and ``Resnet`` use PyTorch ops throughout.
+head stays a PyTorch op.  At other patch sizes, inference (``torch.no_grad``) runs conv3-5 + pooling on the tiled
+HIP kernels (``_hip_inference_trunk``) and training uses PyTorch ops; CPU tensors and ``Resnet`` use PyTorch ops.
 """
 import torch
 import torch.nn as nn
@@ -91,11 +92,32 @@ class CNN(nn.Module):
                                     c[3].weight, c[3].bias, c[4].weight, c[4].bias,
                                     3 if self.hip_convs == "bf16x3" else 1)
             return self.fc(gap)
+        if (self.hip_convs and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and min(x.shape[-2:]) >= 7):
+            return self.fc(self._hip_inference_trunk(x))
         for name, _, _, pooled in _CNN_STACK:
             x = getattr(self, "relu" + name)(getattr(self, "conv" + name)(x))
             if pooled:
                 x = getattr(self, "pool" + name)(x)
         return self.fc(self.global_avg_pool(x).flatten(1))
+
+    def _hip_inference_trunk(self, x):
+        """Inference (no autograd) at patch sizes other than 16x16 -- e.g. the 32x32 patches of BASELINE config 5:
+        conv1/conv2 (+ReLU+pool, 3 % of the flops) on PyTorch-ROCm, then conv3/conv4/conv5 (+ReLU) and the global
+        average pool on the tiled HIP kernels (`crw_enc_conv3x3_map`: 10x10 output tiles over the feature map).
+        x [P,cin,h,w] -> pooled features [P,128]."""
+        import crw_hip
+        split = 3 if self.hip_convs == "bf16x3" else 1
+        for name in ("1", "2"):
+            x = getattr(self, "pool" + name)(TF.relu(getattr(self, "conv" + name)(x)))
+        P, _, H, W = x.shape
+        pk = [crw_hip.enc_pack_weights(getattr(self, "conv" + n).weight, split) for n in ("3", "4", "5")]
+        xh, xl = crw_hip.enc_pack_input_map(x, split)
+        y3h, y3l, _ = crw_hip.enc_conv3x3_map(split, xh, xl, pk[0][0], pk[0][1], 64, H, W, bias=self.conv3.bias)
+        y4h, y4l, _ = crw_hip.enc_conv3x3_map(split, y3h, y3l, pk[1][0], pk[1][1], 128, H, W, bias=self.conv4.bias)
+        _, _, gap = crw_hip.enc_conv3x3_map(split, y4h, y4l, pk[2][0], pk[2][1], 128, H, W, bias=self.conv5.bias,
+                                            planes=False, gap=True)
+        return gap
 
 
 class _Residual(nn.Module):

@@ -175,6 +175,39 @@ def test_full_model_matches_reference(hip, name, wname, convs):
     assert crw_model.CRW(enc, 0.01, bool(g["pos_embed"]), only_a=True).cuda()(dev(g["seq"])).shape == A.shape
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (20, 27), (16, 16), (9, 40)])
+@pytest.mark.parametrize("split", [3, 1])
+def test_encoder_inference_trunk_any_patch_size(hip, hw, split):
+    """CNN inference at patch sizes other than 16x16 (BASELINE config 5 uses 32x32): conv3-5 + ReLU + global
+    average pool on the tiled HIP kernels (10x10 output tiles incl. partial tiles) against the same network in
+    fp64 on the CPU; also the map conv kernel itself (planes) on an odd-sized map."""
+    import encoder as crw_encoder
+    torch.manual_seed(7)
+    enc = crw_encoder.CNN(False)
+    enc.hip_convs = "bf16x3" if split == 3 else "bf16"
+    x = torch.randn(6, 1, *hw)
+    enc64 = crw_encoder.CNN(False).double()
+    enc64.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
+    enc64.hip_convs = None
+    with torch.no_grad():
+        want = enc64(x.double())
+        got = enc.cuda()(x.cuda())
+    tol = dict(rtol=2e-4, atol=2e-5) if split == 3 else dict(rtol=5e-2, atol=5e-3)
+    torch.testing.assert_close(got.cpu().double(), want, **tol)
+    if hw == (20, 27) and split == 3:  # planes of one layer on a 14x21 map (2 x 3 tiles, partial in both directions)
+        import torch.nn.functional as TF
+        g = torch.Generator().manual_seed(3)
+        xm = torch.randn(3, 32, 14, 21, generator=g)
+        w = torch.randn(64, 32, 3, 3, generator=g) * 0.08
+        b = torch.randn(64, generator=g) * 0.1
+        fh, fl, _, _ = hip.enc_pack_weights(w.cuda(), 3)
+        xh, xl = hip.enc_pack_input_map(xm.cuda(), 3)
+        yh, yl, gap = hip.enc_conv3x3_map(3, xh, xl, fh, fl, 64, 14, 21, bias=b.cuda(), gap=False)
+        xq = (xh.float() + xl.float()).cpu().double().reshape(3, 14, 21, 32).permute(0, 3, 1, 2)
+        y_ref = TF.relu(TF.conv2d(xq, w.double(), b.double(), padding=1)).permute(0, 2, 3, 1).reshape(3, 14 * 21, 64)
+        torch.testing.assert_close((yh.float() + yl.float()).cpu().double(), y_ref, rtol=5e-5, atol=5e-5)
+
+
 def test_full_model_at_baseline_shape_vs_oracle(hip):
     """One item of BASELINE configs[2] ([T,N] = [32,63], 16x16 patches, 2016 patches through the whole HIP conv
     trunk + affinity + walk) against the CPU oracle: loss within 1e-4 relative (the north_star tolerance), every
@@ -519,6 +552,35 @@ def test_bidirectional_segmentation_pipeline_matches_oracle(hip):
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), f"{(got != ref).sum()} of {ref.size} pixels differ"
     assert (rev == 2).any() and (fwd != ref).any()  # the merge really changed something
+
+
+def test_propagate_with_cnn_at_32x32_patches_vs_oracle(hip):
+    """BASELINE config 5 in small: 32x32 patches, overlap (24,0), the real CNN encoder whose conv3-5 run on the tiled
+    HIP kernels at this patch size, user-seed label propagation -- against the CPU oracle fed with the fp64 CPU
+    features of the same network (label maps must agree except at numerical near-ties: >= 99 %)."""
+    import dataset as crw_dataset
+    import encoder as crw_encoder
+    import utils as crw_utils
+    from imported.labelprop import LabelPropVOS_CRW
+    T, M = 12, 4
+    ds = crw_dataset.RGDataset.synthetic(130, 32 * T, T, (32, 32), (24, 0), seed=9)
+    seq = ds[0]                                  # [T, N, 32, 32]
+    N = seq.shape[1]
+    rows = N * 8 + 24
+    seg = (torch.arange(rows)[:, None] * M // rows).float().repeat(1, 32)
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    enc64 = crw_encoder.CNN(False).double()
+    enc64.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
+    enc64.hip_convs = None
+    with torch.no_grad():
+        emb = enc64(seq.reshape(-1, 32, 32).unsqueeze(1).double()).reshape(T, N, -1).float().numpy()
+    cfg = dict(CXT_SIZE=5, RADIUS=4, TEMP=0.1, KNN=5)
+    ref = orc.labelprop(emb, orc.seed_labels(seg.numpy(), N), M,
+                        cfg["CXT_SIZE"], cfg["RADIUS"], cfg["TEMP"], cfg["KNN"])
+    pred, xent, _ = crw_utils.propagate(seq.cuda(), seg.cuda(), enc.cuda().eval(), LabelPropVOS_CRW(cfg), M, False, False)
+    agree = float((pred.cpu().numpy() == ref).mean())
+    assert pred.shape == (N, T) and agree >= 0.99, agree
 
 
 def test_no_cpu_fallback(hip):
