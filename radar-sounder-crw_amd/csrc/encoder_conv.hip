@@ -10,22 +10,24 @@
 //
 // Layout: activations live in HBM as compact channels-last bf16 planes [P][100][C] (hi and lo).
 // In LDS a patch is a 12x12 image with a one-pixel zero halo (zeroed once, never loaded), so a tap
-// is a constant pixel offset and no border predication exists.  One
-// workgroup = one patch: the patch (all channels, both planes) is loaded into LDS once and serves
-// all 9 taps x all output channels; rows are XOR-swizzled by pixel so the 16 pixels of an MFMA row
-// tile hit distinct banks.  Waves split the output channels; weight fragments ([tap][co][ci], 16 B
-// per lane) stream straight from L2 into registers, prefetched one k-step ahead.  The epilogue
-// stages the output tile through the same LDS and writes whole 16-byte chunks.
+// is a constant pixel offset and no border predication exists.  One workgroup = one patch: the patch
+// (all channels, both planes) is loaded into LDS once and serves all 9 taps x all output channels; pixel
+// rows are padded (stride 2C+32 bytes) so the lane groups of a fragment read hit distinct banks.  Waves
+// split the output channels; weight fragments (pre-packed in MFMA fragment order, 1 KiB contiguous per
+// wave-instruction) stream straight from L2 into rotating register sets 4 k-steps ahead, activation
+// fragments are read 3 row tiles ahead of their MFMAs.  The epilogue stages the output tile through the
+// same LDS and writes whole 16-byte chunks.
 //
 // The same kernel is the backward-data pass: dX = conv(dY, W flipped, ci <-> co), with the ReLU
-// mask of the layer below applied in the epilogue instead of bias + ReLU.
+// mask of the layer below applied in the epilogue instead of bias + ReLU; and, as the MAP variant, the
+// forward pass on feature maps of any size (10x10 output tiles, window gathered from the map).
 //
 // conv3x3_wgrad_kernel: dW[co,ci,tap] = sum_{p,pix} dY[p,pix,co] * X[p,pix+tap,ci]: both operands
 // are pixel-major in memory, i.e. strided along the reduction dimension, so fragments come from
 // LDS through the hardware-transposing ds_read_b64_tr_b16.  One workgroup owns all 9 taps x 64
 // output channels x a group of (up to) 64 input channels, walks a slice of the patches accumulating in
-// registers, and writes its partial sums to a workspace; a second kernel adds the slices in a
-// fixed order (bitwise reproducible, no float atomics).
+// registers (k-steps of 32 pixels streamed across patch boundaries), and writes its partial sums to a
+// workspace; a second kernel adds the slices in a fixed order (bitwise reproducible, no float atomics).
 #include "crw_common.h"
 #include <type_traits>
 #include <cstdlib>
