@@ -348,7 +348,7 @@ def bench_labelprop(args):
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                       "data": "synthetic", "dtype": "f32",
                       "config": {"workload": f"{H}x{W} radargram, 32x32 patches overlap (24,0) -> [T,N]=[{T},{N}], {cfg}, "
-                                             "CNN encoder (conv1/conv2 on PyTorch-ROCm, conv3-5 + pooling on the tiled HIP kernels) + normalise + xent + top-k + gather"},
+                                             "CNN encoder (whole conv trunk on the tiled HIP kernels, FC head on PyTorch-ROCm) + normalise + xent + top-k + gather"},
                       "labelprop_only": {"ms": dlp * 1e3, "columns_per_s": W / dlp,
                                          "what": "crw_labelprop_topk + crw_labelprop_gather, features resident"},
                       "cpu_baseline": {"value": W / dcpu, "unit": "radargram columns/s", "kind": "port", "cores": torch.get_num_threads(),

@@ -165,6 +165,11 @@ int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint
 int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
                       const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi,
                       uint16_t *y_lo, crw_stream_t stream);
+/* The same front end on patches of any size h, w >= 7 (forward only, inference): x [P][cin][H][W] -> planes
+ * [P][(H-6)*(W-6)][32] that feed crw_enc_conv3x3_map.  Work item = (patch, 10x10 tile of the output map). */
+int crw_enc_front_fwd_map(int split, const float *x, int P, int cin, int H, int W, const float *w1, const float *b1,
+                          const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi, uint16_t *y_lo,
+                          crw_stream_t stream);
 /* backward (recomputes the forward per patch): dy [P][100][32] fp32 -> dw1 [8][cin][5][5], db1 [8],
  * dw2 [32][8][5][5], db2 [32]; partial sums per patch slice in `ws`, added in a fixed order. */
 size_t crw_enc_front_ws_bytes(int P, int cin);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_enc_front_pack": (_c_int, [_p, _p, _p, _p, _p, _p]),
     "crw_enc_front_fwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_front_fwd_map": (_c_int, [_c_int, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_front_ws_bytes": (_c_sz, [_c_int, _c_int]),
     "crw_enc_front_bwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _c_sz, _p]),
@@ -313,6 +314,17 @@ def enc_front_fwd(split, x, w1, b1, w2f, b2):
     _check(lib().crw_enc_front_fwd(split, _dev(x, "x"), P, cin, _dev(w1.contiguous(), "w1"), _dev(b1, "b1"),
                                    _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"), _bf(yh, "yh"), _bf(yl, "yl"),
                                    _stream()), "crw_enc_front_fwd")
+    return yh, yl
+
+
+def enc_front_fwd_map(split, x, w1, b1, w2f, b2):
+    """front end on patches of any size: x [P,cin,H,W] -> planes [P, (H-6)*(W-6), 32] (hi, lo | None)."""
+    P, cin, H, W = x.shape
+    yh = torch.empty(P, (H - 6) * (W - 6), 32, dtype=_BF, device=x.device)
+    yl = torch.empty_like(yh) if split == 3 else None
+    _check(lib().crw_enc_front_fwd_map(split, _dev(x.contiguous(), "x"), P, cin, H, W, _dev(w1.contiguous(), "w1"),
+                                       _dev(b1, "b1"), _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"),
+                                       _bf(yh, "yh"), _bf(yl, "yl"), _stream()), "crw_enc_front_fwd_map")
     return yh, yl
 
 

@@ -205,6 +205,107 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
   }
 }
 
+// ---- the same front end on patches of any size (inference) -------------------------------------------------------
+// A work item = (patch, 10x10 tile of the pool2 output map [H-6][W-6]).  The tile's receptive field is a 20x20
+// window of the patch (zeros outside it): conv1 over 16x16 positions, pool1 over the 15x15 a1 window that conv2
+// needs -- where an a1 position lies outside the a1 map [H-3][W-3] it holds the zero padding of conv2 instead --
+// then conv2 / pool2 exactly as in the 16x16 kernel.  Output: planes [P][(H-6)*(W-6)][32] for crw_enc_conv3x3_map.
+constexpr int MXW = 20, MC1W = 16;  // window / conv1 extent of a tile
+
+struct FrontMapArgs {
+  FrontArgs f;     // x: [P][cin][H][W]; yh/yl: [P][(H-6)*(W-6)][32]
+  int H, W, tiles_x, tiles_y;
+};
+
+template <int SPLIT>
+__global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int cin = a.f.cin, tid = threadIdx.x;
+  char *p = lds;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
+  FwdLds L;
+  L.xs = (float *)take(sizeof(float) * cin * MXW * MXW);
+  L.w1 = (float *)take(sizeof(float) * (8 * cin * 25 + 8));
+  L.c1r = (float *)take(sizeof(float) * MC1W * MC1W * 8);
+  L.a1h = take(A1PW * A1PW * 16);
+  L.a1l = take(A1PW * A1PW * 16);
+  L.w2h = take(KS2 * 32 * 32 * 2);
+  L.w2l = take(KS2 * 32 * 32 * 2);
+  L.c2r = (float *)take(sizeof(float) * C2N * 32);
+  for (int e = tid; e < 8 * cin * 25; e += NTH) {  // [co][ci][tap] -> [ci][tap][co]
+    const int t = e % 25, ci = (e / 25) % cin, co = e / (25 * cin);
+    L.w1[(ci * 25 + t) * 8 + co] = a.f.w1[e];
+  }
+  if (tid < 8) L.w1[8 * cin * 25 + tid] = a.f.b1[tid];
+  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
+    reinterpret_cast<uint4 *>(L.w2h)[e] = reinterpret_cast<const uint4 *>(a.f.w2h)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[e] = reinterpret_cast<const uint4 *>(a.f.w2l)[e];
+  }
+  const float b2r = a.f.b2[16 * ((tid >> 6) & 1) + (tid & 15)];
+  const int H = a.H, W = a.W, Ho = H - 6, Wo = W - 6, ntile = a.tiles_x * a.tiles_y;
+  const long nwork = (long)a.f.P * ntile;
+  __syncthreads();
+  for (long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+    const int pt = (int)(wk / ntile), tile = (int)(wk % ntile);
+    const int oy0 = (tile / a.tiles_x) * OW, ox0 = (tile % a.tiles_x) * OW;
+    // 20x20 window of the patch: local (r, c) = image (oy0 + r - 2, ox0 + c - 2)
+    for (int e = tid; e < cin * MXW * MXW; e += NTH) {
+      const int ci = e / (MXW * MXW), r = (e / MXW) % MXW, c = e % MXW;
+      const int iy = oy0 + r - 2, ix = ox0 + c - 2;
+      L.xs[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? a.f.x[(((long)pt * cin + ci) * H + iy) * W + ix] : 0.f;
+    }
+    lds_barrier();
+    if (tid < MC1W * MC1W * 2) {  // conv1 + bias + ReLU over the 16x16 window: thread = (position, 4 of 8 channels)
+      const int pix = tid >> 1, c0 = 4 * (tid & 1);
+      const int y = pix / MC1W, xx = pix % MC1W;
+      float4 acc = *reinterpret_cast<const float4 *>(L.w1 + 8 * cin * 25 + c0);
+      for (int ci = 0; ci < cin; ++ci) {
+        const float *xs = L.xs + (ci * MXW + y) * MXW + xx;
+        const float *w = L.w1 + ci * 25 * 8 + c0;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+          const float v = xs[(t / 5) * MXW + t % 5];
+          const float4 wv = *reinterpret_cast<const float4 *>(w + t * 8);
+          acc.x = fmaf(v, wv.x, acc.x);
+          acc.y = fmaf(v, wv.y, acc.y);
+          acc.z = fmaf(v, wv.z, acc.z);
+          acc.w = fmaf(v, wv.w, acc.w);
+        }
+      }
+      *reinterpret_cast<float4 *>(L.c1r + pix * 8 + c0) = float4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+    }
+    lds_barrier();
+    // pool1 over the whole 15x15 a1 window: local (r, c) = a1 map (oy0 + r - 1, ox0 + c - 1); outside the map = conv2's zero padding
+    for (int e = tid; e < A1PW * A1PW * 8; e += NTH) {
+      const int c = e & 7, q = e >> 3, r = q / A1PW, cc = q % A1PW;
+      const int ay = oy0 + r - 1, ax = ox0 + cc - 1;
+      float v = 0.f;
+      if (ay >= 0 && ay < H - 3 && ax >= 0 && ax < W - 3) {
+        const float *s1 = L.c1r + (r * MC1W + cc) * 8 + c;
+        v = fmaxf(fmaxf(s1[0], s1[8]), fmaxf(s1[MC1W * 8], s1[MC1W * 8 + 8]));
+      }
+      const uint16_t h = f2bf(v);
+      *reinterpret_cast<uint16_t *>(L.a1h + q * 16 + 2 * c) = h;
+      if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + q * 16 + 2 * c) = f2bf(v - bf2f(h));
+    }
+    lds_barrier();
+    conv2_relu<SPLIT>(L, b2r, tid);
+    lds_barrier();
+    for (int e = tid; e < ON * 32; e += NTH) {  // maxpool 2x2/1 -> the in-map part of the output tile
+      const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
+      if (oy0 + y < Ho && ox0 + x < Wo) {
+        const float *s2 = L.c2r + (y * C2W + x) * 32 + c;
+        const float v = fmaxf(fmaxf(s2[0], s2[32]), fmaxf(s2[C2W * 32], s2[C2W * 32 + 32]));
+        const uint16_t h = f2bf(v);
+        const long o = (((long)pt * Ho + oy0 + y) * Wo + ox0 + x) * 32 + c;
+        a.f.yh[o] = h;
+        if (SPLIT == 3) a.f.yl[o] = f2bf(v - bf2f(h));
+      }
+    }
+    // the next iteration's first barrier orders these c2r reads before conv2_relu overwrites it
+  }
+}
+
 // fp32 conv2 weight [32][8][5][5] -> forward planes [7][32 co][32 k] (k = 8*(tap-4s) + ci, zero beyond tap 24)
 //                                 -> backward planes [25 tap][8 ci][32 co]
 __global__ __launch_bounds__(256) void pack_w2_kernel(const float *__restrict__ w, uint16_t *fh, uint16_t *fl,
@@ -619,6 +720,34 @@ int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1
   const int grid = P < 512 ? P : 512;  // two 1024-thread workgroups (60 KB of LDS each) per CU
   if (split == 3) hipLaunchKernelGGL(front_fwd_kernel<3>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(front_fwd_kernel<1>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+// front end on patches of any size (h, w >= 7), forward only: x [P][cin][H][W] -> planes [P][(H-6)*(W-6)][32]
+int crw_enc_front_fwd_map(int split, const float *x, int P, int cin, int H, int W, const float *w1, const float *b1,
+                          const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi, uint16_t *y_lo,
+                          crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !w1 || !b1 || !w2_hi || !b2 || !y_hi || P < 1 || (cin != 1 && cin != 2) || (split != 1 && split != 3) || H < 7 ||
+      W < 7)
+    return CRW_EINVAL;
+  if (split == 3 && (!w2_lo || !y_lo)) return CRW_EINVAL;
+  const int tx = (W - 6 + OW - 1) / OW, ty = (H - 6 + OW - 1) / OW;
+  FrontMapArgs a{{x, w1, b1, w2_hi, w2_lo, b2, y_hi, y_lo, P, cin}, H, W, tx, ty};
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const size_t lds = r(4 * cin * MXW * MXW) + r(4 * (8 * cin * 25 + 8)) + r(4 * MC1W * MC1W * 8) + 2 * r(A1PW * A1PW * 16) +
+                     2 * r(KS2 * 32 * 32 * 2) + r(4 * C2N * 32);
+  const long nwork = (long)P * tx * ty;
+  const int grid = nwork < 512 ? (int)nwork : 512;  // two 1024-thread workgroups per CU
+  static bool attr3 = false, attr1 = false;
+  bool &attr = split == 3 ? attr3 : attr1;
+  const void *fn = split == 3 ? (const void *)front_fwd_map_kernel<3> : (const void *)front_fwd_map_kernel<1>;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CRW_EHIP;
+    attr = true;
+  }
+  if (split == 3) hipLaunchKernelGGL(front_fwd_map_kernel<3>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(front_fwd_map_kernel<1>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
   return check_launch();
 }
 

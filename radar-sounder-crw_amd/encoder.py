@@ -103,16 +103,17 @@ class CNN(nn.Module):
 
     def _hip_inference_trunk(self, x):
         """Inference (no autograd) at patch sizes other than 16x16 -- e.g. the 32x32 patches of BASELINE config 5:
-        conv1/conv2 (+ReLU+pool, 3 % of the flops) on PyTorch-ROCm, then conv3/conv4/conv5 (+ReLU) and the global
-        average pool on the tiled HIP kernels (`crw_enc_conv3x3_map`: 10x10 output tiles over the feature map).
+        the whole conv trunk on the tiled HIP kernels -- fused conv1-ReLU-pool-conv2-ReLU-pool (`crw_enc_front_fwd_map`),
+        then conv3/conv4/conv5 (+ReLU) and the global average pool (`crw_enc_conv3x3_map`), all on 10x10 output
+        tiles over the feature map.
         x [P,cin,h,w] -> pooled features [P,128]."""
         import crw_hip
         split = 3 if self.hip_convs == "bf16x3" else 1
-        for name in ("1", "2"):
-            x = getattr(self, "pool" + name)(TF.relu(getattr(self, "conv" + name)(x)))
-        P, _, H, W = x.shape
+        P, _, h, w = x.shape
+        H, W = h - 6, w - 6  # conv3-5 feature map
+        w2p = crw_hip.enc_front_pack(self.conv2.weight, split)
+        xh, xl = crw_hip.enc_front_fwd_map(split, x, self.conv1.weight, self.conv1.bias, w2p[:2], self.conv2.bias)
         pk = [crw_hip.enc_pack_weights(getattr(self, "conv" + n).weight, split) for n in ("3", "4", "5")]
-        xh, xl = crw_hip.enc_pack_input_map(x, split)
         y3h, y3l, _ = crw_hip.enc_conv3x3_map(split, xh, xl, pk[0][0], pk[0][1], 64, H, W, bias=self.conv3.bias)
         y4h, y4l, _ = crw_hip.enc_conv3x3_map(split, y3h, y3l, pk[1][0], pk[1][1], 128, H, W, bias=self.conv4.bias)
         _, _, gap = crw_hip.enc_conv3x3_map(split, y4h, y4l, pk[2][0], pk[2][1], 128, H, W, bias=self.conv5.bias,
