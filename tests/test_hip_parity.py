@@ -395,6 +395,30 @@ def test_encoder_kernels_full_size_by_replication(hip, cin, cout):
             torch.testing.assert_close(a_, b_ * reps, rtol=2e-4, atol=2e-4 * (b_.abs().max().item() * reps))
 
 
+@pytest.mark.parametrize("reps", [25, 37, 129])
+@pytest.mark.parametrize("split", [3, 1])
+def test_wgrad_patch_slice_lengths(hip, reps, split):
+    """Weight gradient with 2, 3 and 9 patches per workgroup slice (P = 200, 296, 1032 against 128 slices): the
+    k-steps that stream across patch boundaries end with 8, 0 or 0 deferred pixels, i.e. with and without the final
+    flush step.  Checked by replication: gradients must be `reps` times those of the 8 distinct patches."""
+    P0, cin, cout = 8, 128, 128
+    g = torch.Generator().manual_seed(reps)
+    xp = (torch.randn(P0, 100, cin, generator=g) * 0.5).cuda()
+    dyp = (torch.randn(P0, 100, cout, generator=g) * 0.5).cuda()
+    hl = lambda t: (t.bfloat16(), (t - t.bfloat16().float()).bfloat16() if split == 3 else None)
+    (xh, xl), (dh, dl) = hl(xp), hl(dyp)
+    rep = lambda t: None if t is None else t.repeat(reps, 1, 1).contiguous()
+    dw_s, db_s = hip.enc_wgrad(split, dh, dl, xh, xl)
+    dw_f, db_f = hip.enc_wgrad(split, rep(dh), rep(dl), rep(xh), rep(xl))
+    torch.testing.assert_close(dw_f, dw_s * reps, rtol=2e-4, atol=2e-4 * (dw_s.abs().max().item() * reps))
+    torch.testing.assert_close(db_f, db_s * reps, rtol=2e-4, atol=2e-4 * (db_s.abs().max().item() * reps))
+    # and against fp64 on the 8 distinct patches
+    xq = ((xh.float() + (xl.float() if xl is not None else 0)).cpu().double()).reshape(P0, 10, 10, cin).permute(0, 3, 1, 2)
+    dq = ((dh.float() + (dl.float() if dl is not None else 0)).cpu().double()).reshape(P0, 10, 10, cout).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xq, (cout, cin, 3, 3), dq, padding=1)
+    torch.testing.assert_close(dw_s.cpu().double(), ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item())
+
+
 @pytest.mark.parametrize("cin", [1, 2])
 @pytest.mark.parametrize("split", [3, 1])
 def test_encoder_front_kernels_match_torch(hip, cin, split):
