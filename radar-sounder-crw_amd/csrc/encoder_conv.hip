@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient.  grid = (ci groups x co groups, patch slices); 256 threads = 4 waves (see the kernel).
+// weight gradient.  1-D grid over (patch slice, channel group); 4 or 8 waves per workgroup (see the kernel).
 struct WgradArgs {
   const uint16_t *dyh, *dyl;  // [P][100][COUT] masked output gradient planes
   const uint16_t *xh, *xl;    // [P][100][CIN] layer input planes
@@ -1109,7 +1109,7 @@ static int wgrad_groups(int cin) { return cin / wgrad_nci(cin); }
 static int wgrad_slices(int P, int cin, int cout, int split) {
   (void)split;
   const int groups = wgrad_groups(cin) * (cout / WG_NCO);  // workgroups per slice
-  int n = 256 * 2 / (groups < 1 ? 1 : groups);             // two workgroups of 256 threads per CU
+  int n = 256 * 2 / (groups < 1 ? 1 : groups);             // two workgroups per CU on the 256 CUs of an MI355X
   return n > P ? P : n;
 }
 

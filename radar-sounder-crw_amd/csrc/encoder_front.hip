@@ -1,8 +1,8 @@
 // Fused front end of the CNN encoder (src/encoder.py:13-24,46-47):
 //     x [cin,16,16] -> conv1 5x5 pad 1 (cin->8) -> ReLU -> maxpool 2x2/1 -> conv2 5x5 pad 1 (8->32)
 //       -> ReLU -> maxpool 2x2/1 -> [100][32] channels-last bf16 planes (hi[,lo]) for conv3.
-// One persistent workgroup (256 threads) streams patches; everything between the 1 KB input patch
-// and the 6.4 KB output planes stays in LDS.
+// One persistent workgroup (1024 threads = 16 waves) streams patches, the next patch prefetched into registers;
+// everything between the 1 KB input patch and the 6.4 KB output planes stays in LDS.
 //   conv1 (25*cin MACs per output, 3 % of this stage): fp32 VALU, exact.
 //   conv2 (200 MACs per output): implicit GEMM on v_mfma_f32_16x16x32_bf16 with k = (tap, ci): one
 //     32-deep k-step = 4 taps x 8 input channels, so an A fragment is ONE 16-byte channels-last read
