@@ -16,7 +16,7 @@
 //        fragments by two ds_read_b64_tr_b16 (hardware transpose), so transposed operands of the
 //        chain (Lt^T R, Gt^T dLt, ...) never need a transposed copy in HBM.
 // Double-buffered: the DMA of k-tile t+1 is in flight while the MFMAs of tile t run; one barrier
-// per k-tile.
+// per k-tile.  Tiles are 128x128 (4 waves) or 256x256 (8 waves, plain bf16 when the grid still fills the chip).
 #include "crw_common.h"
 
 namespace crw {
@@ -105,13 +105,23 @@ struct Cfg<128> { static constexpr int TB = 128, WAVES = 4, WN = 2, FM = 4, FN =
 template <>
 struct Cfg<256> { static constexpr int TB = 256, WAVES = 8, WN = 4, FM = 8, FN = 4; };
 
+// Stages of the LDS-DMA ring: two everywhere.  At 128 x 128 / plain bf16 a stage is 32 KiB, so two stages leave room for
+// TWO workgroups per CU; measured at n = 4096 that beats one workgroup with a 4-stage ring (800 vs 605 TFLOP/s):
+// a second workgroup covers DMA waits better than a deeper ring does.
+template <int SPLIT, int TB>
+constexpr int ring_stages() {
+  return 2;
+}
+template <int SPLIT, int TB>
+constexpr size_t ring_bytes() { return (size_t)ring_stages<SPLIT, TB>() * ((SPLIT == 3) ? 4 : 2) * TB * 128; }
+
 template <int SPLIT, int TB, bool AKC, bool BKC>
 __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0,
                                 int n0, char *lds, int wave, int lane) {
   using C = Cfg<TB>;
   constexpr int IMG = TB * 128;                 // bytes per image
   constexpr int NIMG = (SPLIT == 3) ? 4 : 2;    // images per stage: A(hi[,lo]) B(hi[,lo])
-  constexpr int NSTAGE = (128 * 1024) / (NIMG * IMG) >= 4 ? 4 : 2;  // 128 KiB of LDS either way
+  constexpr int NSTAGE = ring_stages<SPLIT, TB>();
   constexpr int G = (TB / 8 / C::WAVES) * NIMG;  // LDS-DMA instructions per wave per k-tile
   const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
   const int nt = n / BKB;
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(Gemm
 template <int SPLIT, int TB, bool AKC, bool BKC>
 int launch_one(const GemmGroup &g, hipStream_t s) {
   static bool attr_set = false;
-  const size_t lds = 128 * 1024;
+  const size_t lds = ring_bytes<SPLIT, TB>();
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
