@@ -93,6 +93,36 @@ struct PlaneLoad {
   }
 };
 
+// Pieces of the fused ReLU5 + global-average-pool backward (dY = dgap / 100 where the forward activation is
+// non-zero).  A thread always handles the same 8 channels, so it splits dgap/100 into packed hi/lo bf16 pairs
+// once per patch (gap_split8) and each pixel chunk only masks the pairs with "activation != 0" (gap_mask8).
+// Contraction is off: these loaders and gap_bwd_kernel must round alike (no a*b - c fused in one of them).
+__device__ inline void gap_split8(const float *__restrict__ dg8, uint32_t (&gh)[4], uint32_t (&gl)[4]) {
+#pragma clang fp contract(off)
+  const float4 g0 = *reinterpret_cast<const float4 *>(dg8);
+  const float4 g1 = *reinterpret_cast<const float4 *>(dg8 + 4);
+  const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float a0 = gv[2 * w] * (1.0f / NPIX), a1 = gv[2 * w + 1] * (1.0f / NPIX);
+    const uint16_t h0 = f2bf(a0), h1 = f2bf(a1);
+    gh[w] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    gl[w] = (uint32_t)f2bf(a0 - bf2f(h0)) | ((uint32_t)f2bf(a1 - bf2f(h1)) << 16);
+  }
+}
+__device__ inline void gap_mask8(const uint4 &y, const uint32_t (&gh)[4], const uint32_t (&gl)[4], uint4 &oh, uint4 &ol) {
+  const uint32_t yw[4] = {y.x, y.y, y.z, y.w};
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t m = ((yw[w] & 0x7fffu) ? 0xffffu : 0u) | ((yw[w] & 0x7fff0000u) ? 0xffff0000u : 0u);
+    h[w] = gh[w] & m;
+    l[w] = gl[w] & m;
+  }
+  oh = uint4{h[0], h[1], h[2], h[3]};
+  ol = uint4{l[0], l[1], l[2], l[3]};
+}
+
 // Fused ReLU5 + global-average-pool backward: the gradient planes of the last conv layer are never
 // materialised; dY[i][c] = dgap[c] / 100 where the forward activation y[i][c] (hi plane) is non-zero.
 // Loads the activation chunks, builds the hi/lo planes of dY directly in LDS.
@@ -106,39 +136,19 @@ __device__ inline void gap_planes_to_lds(const uint16_t *__restrict__ yh, const 
     const int c = min(tid + i * NTHREADS, TOTAL - 1);  // clamped, unconditional (see PlaneLoad)
     v[i] = *reinterpret_cast<const uint4 *>(yh + (long)c * 8);
   }
-  // the thread's channel chunk is the same for all its pixels (NTHREADS % NCH == 0): split dgap/100 into hi/lo
-  // bf16 once per patch, then a pixel only masks the packed pairs with "activation != 0"
-  static_assert(NTHREADS % NCH == 0, "chunk per thread");
+  static_assert(NTHREADS % NCH == 0, "a thread keeps its channel chunk");
   const int ch = tid % NCH;
   uint32_t gh[4], gl[4];
-  {
-#pragma clang fp contract(off)  // the fused loaders and gap_bwd_kernel must round alike (no a*b - c fusion in one of them)
-    const float4 g0 = *reinterpret_cast<const float4 *>(dgap_row + 8 * ch);
-    const float4 g1 = *reinterpret_cast<const float4 *>(dgap_row + 8 * ch + 4);
-    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float a0 = gv[2 * w] * (1.0f / NPIX), a1 = gv[2 * w + 1] * (1.0f / NPIX);
-      const uint16_t h0 = f2bf(a0), h1 = f2bf(a1);
-      gh[w] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-      gl[w] = (uint32_t)f2bf(a0 - bf2f(h0)) | ((uint32_t)f2bf(a1 - bf2f(h1)) << 16);
-    }
-  }
+  gap_split8(dgap_row + 8 * ch, gh, gl);
 #pragma unroll
   for (int i = 0; i < ITER; ++i) {
     const int c = tid + i * NTHREADS;
     if (TOTAL % NTHREADS == 0 || c < TOTAL) {
-      const uint32_t yw[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-      uint32_t oh[4], ol[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const uint32_t m = ((yw[w] & 0x7fffu) ? 0xffffu : 0u) | ((yw[w] & 0x7fff0000u) ? 0xffff0000u : 0u);
-        oh[w] = gh[w] & m;
-        ol[w] = gl[w] & m;
-      }
+      uint4 oh, ol;
+      gap_mask8(v[i], gh, gl, oh, ol);
       const int off = interior_pp(c / NCH) * RS + 16 * ch;
-      *reinterpret_cast<uint4 *>(dst_hi + off) = uint4{oh[0], oh[1], oh[2], oh[3]};
-      if (SPLIT == 3) *reinterpret_cast<uint4 *>(dst_lo + off) = uint4{ol[0], ol[1], ol[2], ol[3]};
+      *reinterpret_cast<uint4 *>(dst_hi + off) = oh;
+      if (SPLIT == 3) *reinterpret_cast<uint4 *>(dst_lo + off) = ol;
     }
   }
 }
@@ -726,39 +736,19 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
         }
       if (a.dgap) {
         // dY[i][c] = dgap[c] / 100 where the forward activation (hi plane, in yv[0]) is non-zero
-        // (channel chunk fixed per thread: dgap/100 is split into hi/lo once per patch, pixels only mask it)
-        static_assert(NTH % YCH == 0, "chunk per thread");
-        const float *dg = a.dgap + (long)p * COUT + co_base;
+        static_assert(NTH % YCH == 0, "a thread keeps its channel chunk");
         const int ch = tid % YCH;
         uint32_t gh[4], gl[4];
-        {
-#pragma clang fp contract(off)  // same rounding as gap_bwd_kernel / gap_planes_to_lds
-          const float4 g0 = *reinterpret_cast<const float4 *>(dg + 8 * ch);
-          const float4 g1 = *reinterpret_cast<const float4 *>(dg + 8 * ch + 4);
-          const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const float a0 = gv[2 * w] * (1.0f / NPIX), a1 = gv[2 * w + 1] * (1.0f / NPIX);
-            const uint16_t h0 = f2bf(a0), h1 = f2bf(a1);
-            gh[w] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            gl[w] = (uint32_t)f2bf(a0 - bf2f(h0)) | ((uint32_t)f2bf(a1 - bf2f(h1)) << 16);
-          }
-        }
+        gap_split8(a.dgap + (long)p * COUT + co_base + 8 * ch, gh, gl);
 #pragma unroll
         for (int i = 0; i < YIT; ++i) {
           const int c = tid + i * NTH;
           if (YTOT % NTH == 0 || c < YTOT) {
-            const uint32_t yw[4] = {yv[0][i].x, yv[0][i].y, yv[0][i].z, yv[0][i].w};
-            uint32_t oh[4], ol[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const uint32_t m = ((yw[w] & 0x7fffu) ? 0xffffu : 0u) | ((yw[w] & 0x7fff0000u) ? 0xffff0000u : 0u);
-              oh[w] = gh[w] & m;
-              ol[w] = gl[w] & m;
-            }
+            uint4 oh, ol;
+            gap_mask8(yv[0][i], gh, gl, oh, ol);
             const int off = (c / YCH) * YS + 16 * ch;
-            *reinterpret_cast<uint4 *>(ys + off) = uint4{oh[0], oh[1], oh[2], oh[3]};
-            if (SPLIT == 3) *reinterpret_cast<uint4 *>(ys + YPL + off) = uint4{ol[0], ol[1], ol[2], ol[3]};
+            *reinterpret_cast<uint4 *>(ys + off) = oh;
+            if (SPLIT == 3) *reinterpret_cast<uint4 *>(ys + YPL + off) = ol;
           }
         }
       } else {

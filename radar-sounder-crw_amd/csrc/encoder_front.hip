@@ -336,7 +336,7 @@ struct FrontBwdArgs {
   int patches_per_block;
   long long *stamps;         // `make STAMPS=1` builds: [grid][NPHASE] cycles per phase summed over the slice (else null)
 };
-constexpr int NPHASE = 10;
+[[maybe_unused]] constexpr int NPHASE = 10;
 #ifdef CRW_CONV_STAMPS
 #define FRONT_STAMP(k)                                                       \
   if (a.stamps && tid == 0) {                                                \
