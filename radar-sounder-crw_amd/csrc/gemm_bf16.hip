@@ -22,15 +22,24 @@
 namespace crw {
 namespace {
 
-constexpr int BKB = 64;  // k-tile
+// k-tile depth BK: 64, except 32 for 256x256 tiles of hi/lo pairs (halves the 4-image stage to 64 KiB so that two stages
+// and 8 waves fit: 1.1 PFLOP/s of MFMA work against 0.84 with 128x128 tiles of 4 waves).  For plain bf16 at 256x256 a
+// 4-stage BK = 32 ring measured slower than the 2-stage BK = 64 ring (858 vs 940 TFLOP/s: twice the barriers).
+template <int SPLIT, int TB>
+constexpr int tile_bk() { return (TB == 256 && SPLIT == 3) ? 32 : 64; }
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) char *lds_cp;
 
-// byte offsets inside an image
-__device__ inline int kc_off(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
+// byte offsets inside an image.  KC rows are 2*BK bytes; the chunk swizzle makes the ds_read_b128 lane groups
+// ({0-3,12-15,20-27}, ...) of a fragment read conflict-free: BK = 64: chunk ^ (row & 7); BK = 32 (4 chunks per
+// row, rows r, r+4, r+8, r+12 share their banks): chunk ^ (row & 8 ? 3 : 0)
+template <int BK>
+__device__ inline int kc_sw(int row) { return BK == 64 ? (row & 7) : ((row & 8) ? 3 : 0); }
+template <int BK>
+__device__ inline int kc_off(int row, int chunk) { return row * (2 * BK) + 16 * (chunk ^ kc_sw<BK>(row)); }
 __device__ inline int rc_sw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 template <int TB>
 __device__ inline int rc_off(int row, int chunk) { return row * (TB * 2) + 16 * (chunk ^ rc_sw(row)); }
@@ -51,19 +60,21 @@ __device__ inline s4v tr_read(uint32_t lds_addr) {
 __device__ inline uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(lds_cp)p; }
 
 // stage one image of an operand tile with TB rows (or TB columns): TB/8 pieces of 1 KiB
-//   KC: [TB rows][64 k]   128-byte rows, 8 rows per piece
-//   RC: [64 k rows][TB]   2*TB-byte rows, 512/TB rows per piece
-template <bool KC, int TB, int WAVES>
+//   KC: [TB rows][BK k]   2*BK-byte rows, 512/BK rows per piece
+//   RC: [BK k rows][TB]   2*TB-byte rows, 512/TB rows per piece
+template <bool KC, int TB, int WAVES, int BK>
 __device__ inline void stage_image(const uint16_t *__restrict__ X, int ld, int r0, int k0, char *img, int wave,
                                    int lane) {
-  constexpr int PIECES = TB / 8, PER = PIECES / WAVES;
+  constexpr int PIECES = TB * BK / 512, PER = PIECES / WAVES;  // 1 KiB pieces of the TB x BK image
+  static_assert(PER >= 1 && PIECES % WAVES == 0, "pieces per wave");
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int piece = WAVES * i + wave;
     const uint16_t *src;
     if (KC) {
-      const int row = 8 * piece + (lane >> 3);
-      const int chunk = (lane & 7) ^ (row & 7);
+      constexpr int LPR = BK / 8;  // lanes (16-byte chunks) per row: 8 or 4
+      const int row = (64 / LPR) * piece + lane / LPR;
+      const int chunk = (lane % LPR) ^ kc_sw<BK>(row);
       src = X + (long)(r0 + row) * ld + k0 + 8 * chunk;
     } else {
       constexpr int LPR = TB / 8;  // lanes (16-byte chunks) per row: 16 or 32
@@ -76,11 +87,11 @@ __device__ inline void stage_image(const uint16_t *__restrict__ X, int ld, int r
 }
 
 // fragment of the 16 rows/cols [rb, rb+16) x k-step s (32 deep) of an image
-template <bool KC, int TB>
+template <bool KC, int TB, int BK>
 __device__ inline bf8 read_frag(const char *img, int rb, int s, int lane) {
   if (KC) {
     const int row = rb + (lane & 15);
-    return *reinterpret_cast<const bf8 *>(img + kc_off(row, 4 * s + (lane >> 4)));
+    return *reinterpret_cast<const bf8 *>(img + kc_off<BK>(row, 4 * s + (lane >> 4)));
   } else {
     const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
     const int row = 32 * s + 8 * g + q;
@@ -105,33 +116,33 @@ struct Cfg<128> { static constexpr int TB = 128, WAVES = 4, WN = 2, FM = 4, FN =
 template <>
 struct Cfg<256> { static constexpr int TB = 256, WAVES = 8, WN = 4, FM = 8, FN = 4; };
 
-// Stages of the LDS-DMA ring: two everywhere.  At 128 x 128 / plain bf16 a stage is 32 KiB, so two stages leave room for
-// TWO workgroups per CU; measured at n = 4096 that beats one workgroup with a 4-stage ring (800 vs 605 TFLOP/s):
-// a second workgroup covers DMA waits better than a deeper ring does.
+// Stages of the LDS-DMA ring: two everywhere.  At 128 x 128 / plain bf16 a stage is 32 KiB, which leaves room for TWO
+// workgroups per CU; measured at n = 4096 that beats one workgroup with a 4-stage ring (800 vs 605 TFLOP/s).
 template <int SPLIT, int TB>
 constexpr int ring_stages() {
   return 2;
 }
 template <int SPLIT, int TB>
-constexpr size_t ring_bytes() { return (size_t)ring_stages<SPLIT, TB>() * ((SPLIT == 3) ? 4 : 2) * TB * 128; }
+constexpr size_t ring_bytes() { return (size_t)ring_stages<SPLIT, TB>() * ((SPLIT == 3) ? 4 : 2) * TB * 2 * tile_bk<SPLIT, TB>(); }
 
 template <int SPLIT, int TB, bool AKC, bool BKC>
 __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0,
                                 int n0, char *lds, int wave, int lane) {
   using C = Cfg<TB>;
-  constexpr int IMG = TB * 128;                 // bytes per image
+  constexpr int BKB = tile_bk<SPLIT, TB>();
+  constexpr int IMG = TB * 2 * BKB;             // bytes per image
   constexpr int NIMG = (SPLIT == 3) ? 4 : 2;    // images per stage: A(hi[,lo]) B(hi[,lo])
   constexpr int NSTAGE = ring_stages<SPLIT, TB>();
-  constexpr int G = (TB / 8 / C::WAVES) * NIMG;  // LDS-DMA instructions per wave per k-tile
+  constexpr int G = (TB * BKB / 512 / C::WAVES) * NIMG;  // LDS-DMA instructions per wave per k-tile
   const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
   const int nt = n / BKB;
   auto stage = [&](int t, int buf) {
     char *base = lds + buf * NIMG * IMG;
-    stage_image<AKC, TB, C::WAVES>(A.hi, n, m0, t * BKB, base, wave, lane);
-    stage_image<BKC, TB, C::WAVES>(B.hi, n, n0, t * BKB, base + IMG, wave, lane);
+    stage_image<AKC, TB, C::WAVES, BKB>(A.hi, n, m0, t * BKB, base, wave, lane);
+    stage_image<BKC, TB, C::WAVES, BKB>(B.hi, n, n0, t * BKB, base + IMG, wave, lane);
     if (SPLIT == 3) {
-      stage_image<AKC, TB, C::WAVES>(A.lo, n, m0, t * BKB, base + 2 * IMG, wave, lane);
-      stage_image<BKC, TB, C::WAVES>(B.lo, n, n0, t * BKB, base + 3 * IMG, wave, lane);
+      stage_image<AKC, TB, C::WAVES, BKB>(A.lo, n, m0, t * BKB, base + 2 * IMG, wave, lane);
+      stage_image<BKC, TB, C::WAVES, BKB>(B.lo, n, n0, t * BKB, base + 3 * IMG, wave, lane);
     }
   };
   // ring of NSTAGE buffers, DMA runs NSTAGE-1 k-tiles ahead of the MFMAs; counted vmcnt + raw
@@ -149,17 +160,17 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
     if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
     const char *base = lds + (t % NSTAGE) * NIMG * IMG;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < BKB / 32; ++s) {
       bf8 a[C::FM], b[C::FN], al[C::FM], bl[C::FN];
 #pragma unroll
       for (int j = 0; j < C::FN; ++j) {
-        b[j] = read_frag<BKC, TB>(base + IMG, wn + 16 * j, s, lane);
-        if (SPLIT == 3) bl[j] = read_frag<BKC, TB>(base + 3 * IMG, wn + 16 * j, s, lane);
+        b[j] = read_frag<BKC, TB, BKB>(base + IMG, wn + 16 * j, s, lane);
+        if (SPLIT == 3) bl[j] = read_frag<BKC, TB, BKB>(base + 3 * IMG, wn + 16 * j, s, lane);
       }
 #pragma unroll
       for (int i = 0; i < C::FM; ++i) {
-        a[i] = read_frag<AKC, TB>(base, wm + 16 * i, s, lane);
-        if (SPLIT == 3) al[i] = read_frag<AKC, TB>(base + 2 * IMG, wm + 16 * i, s, lane);
+        a[i] = read_frag<AKC, TB, BKB>(base, wm + 16 * i, s, lane);
+        if (SPLIT == 3) al[i] = read_frag<AKC, TB, BKB>(base + 2 * IMG, wm + 16 * i, s, lane);
       }
       if (!AKC || !BKC) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -322,10 +333,10 @@ int launch_gemm_group_bf16(const GemmGroup &g, int split, hipStream_t s) {
       }
       if (!sub.nprob) continue;
       // 256 x 256 tiles (half the operand bytes per flop) when they still fill the chip
-      const bool big = split != 3 && (g.n % 256 == 0) &&
-                       ((long)(g.n / 256) * (g.n / 256) * sub.batch * sub.nprob >= 256);
+      const bool big = (g.n % 256 == 0) && ((long)(g.n / 256) * (g.n / 256) * sub.batch * sub.nprob >= 256);
       int st;
-      if (split == 3) st = launch_layout<3, 128>(sub, code, s);
+      // hi/lo pairs: 256 x 256 only when op(A) is k-contiguous (the other two layouts exceed 256 registers there)
+      if (split == 3) st = (big && code >= 2) ? launch_layout<3, 256>(sub, code, s) : launch_layout<3, 128>(sub, code, s);
       else st = big ? launch_layout<1, 256>(sub, code, s) : launch_layout<1, 128>(sub, code, s);
       if (st != CRW_OK) return st;
     }
