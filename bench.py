@@ -437,8 +437,8 @@ def main():
             "metric": "radargram columns/sec (CRW fwd+bwd)", "value": cols_per_step * world / (elapsed / args.steps),
             "unit": "radargram columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16x3": "f32 (conv3-5 and nothing else on bf16 hi/lo pairs, fp32 accumulate: fp32-grade)",
-                      "bf16": "bf16 (conv3-5 operands), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else "torch"],
+            "dtype": {"bf16x3": "f32 (conv2-5 multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; everything else fp32)",
+                      "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else "torch"],
             "data": "synthetic",
             "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
                                    f"[T={T},N={N},16x16] (patch 16x16, overlap {OVERLAP}), tau={TAU}, "
