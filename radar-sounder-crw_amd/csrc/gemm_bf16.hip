@@ -52,9 +52,10 @@ __device__ inline void glds16(const uint16_t *g, char *lds_wave_base) {
 // The transposed LDS read goes through inline asm: given the builtin, hipcc (ROCm 7.2) drains every
 // in-flight LDS-DMA (s_waitcnt vmcnt(0)) in front of it, which serialises the ring.  The caller
 // issues s_waitcnt lgkmcnt(0) + sched_barrier before the MFMAs that consume the result.
-__device__ inline s4v tr_read(uint32_t lds_addr) {
-  s4v v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+template <int OFF>
+__device__ inline s4v tr_read(uint32_t lds_addr) {  // OFF: image offset inside the stage, an instruction immediate, so
+  s4v v;                                            // the hi and lo planes of an operand share one address register
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
   return v;
 }
 __device__ inline uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(lds_cp)p; }
@@ -87,18 +88,19 @@ __device__ inline void stage_image(const uint16_t *__restrict__ X, int ld, int r
 }
 
 // fragment of the 16 rows/cols [rb, rb+16) x k-step s (32 deep) of an image
-template <bool KC, int TB, int BK>
-__device__ inline bf8 read_frag(const char *img, int rb, int s, int lane) {
+template <bool KC, int TB, int BK, int OFF>
+__device__ inline bf8 read_frag(const char *stage, int rb, int s, int lane) {  // image at stage + OFF
+  static_assert(OFF >= 0 && OFF < 65536, "image offset must fit the DS offset field");
   if (KC) {
     const int row = rb + (lane & 15);
-    return *reinterpret_cast<const bf8 *>(img + kc_off<BK>(row, 4 * s + (lane >> 4)));
+    return *reinterpret_cast<const bf8 *>(stage + OFF + kc_off<BK>(row, 4 * s + (lane >> 4)));
   } else {
     const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
     const int row = 32 * s + 8 * g + q;
     const int chunk = (rb >> 3) + (p >> 1);
-    const uint32_t base = lds_addr_of(img);
-    const s4v lo = tr_read(base + rc_off<TB>(row, chunk) + 8 * (p & 1));
-    const s4v hi = tr_read(base + rc_off<TB>(row + 4, chunk) + 8 * (p & 1));
+    const uint32_t base = lds_addr_of(stage);
+    const s4v lo = tr_read<OFF>(base + rc_off<TB>(row, chunk) + 8 * (p & 1));
+    const s4v hi = tr_read<OFF>(base + rc_off<TB>(row + 4, chunk) + 8 * (p & 1));
     const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf8, v);
   }
@@ -161,31 +163,38 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
     const char *base = lds + (t % NSTAGE) * NIMG * IMG;
 #pragma unroll
     for (int s = 0; s < BKB / 32; ++s) {
-      bf8 a[C::FM], b[C::FN], al[C::FM], bl[C::FN];
+      // B fragments once per k-step; A fragments in groups of 4 row tiles (with 8 row tiles per wave, all 16 hi/lo
+      // A fragments at once push the hi/lo kernels past 256 registers)
+      constexpr int AG = C::FM > 4 ? 4 : C::FM;
+      bf8 b[C::FN], bl[C::FN];
 #pragma unroll
       for (int j = 0; j < C::FN; ++j) {
-        b[j] = read_frag<BKC, TB, BKB>(base + IMG, wn + 16 * j, s, lane);
-        if (SPLIT == 3) bl[j] = read_frag<BKC, TB, BKB>(base + 3 * IMG, wn + 16 * j, s, lane);
+        b[j] = read_frag<BKC, TB, BKB, IMG>(base, wn + 16 * j, s, lane);
+        if constexpr (SPLIT == 3) bl[j] = read_frag<BKC, TB, BKB, 3 * IMG>(base, wn + 16 * j, s, lane);
       }
 #pragma unroll
-      for (int i = 0; i < C::FM; ++i) {
-        a[i] = read_frag<AKC, TB, BKB>(base, wm + 16 * i, s, lane);
-        if (SPLIT == 3) al[i] = read_frag<AKC, TB, BKB>(base + 2 * IMG, wm + 16 * i, s, lane);
-      }
-      if (!AKC || !BKC) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int i0 = 0; i0 < C::FM; i0 += AG) {
+        bf8 a[AG], al[AG];
 #pragma unroll
-      for (int i = 0; i < C::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::FN; ++j) {
-          if (SPLIT == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < AG; ++i) {
+          a[i] = read_frag<AKC, TB, BKB, 0>(base, wm + 16 * (i0 + i), s, lane);
+          if constexpr (SPLIT == 3) al[i] = read_frag<AKC, TB, BKB, 2 * IMG>(base, wm + 16 * (i0 + i), s, lane);
         }
+        if (!AKC || !BKC) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+#pragma unroll
+          for (int j = 0; j < C::FN; ++j) {
+            if (SPLIT == 3) {
+              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i0 + i][j], 0, 0, 0);
+              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+            }
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i0 + i][j], 0, 0, 0);
+          }
+      }
     }
   }
   __syncthreads();  // the second product (or the next use of LDS) may restage buffer 0
@@ -335,8 +344,7 @@ int launch_gemm_group_bf16(const GemmGroup &g, int split, hipStream_t s) {
       // 256 x 256 tiles (half the operand bytes per flop) when they still fill the chip
       const bool big = (g.n % 256 == 0) && ((long)(g.n / 256) * (g.n / 256) * sub.batch * sub.nprob >= 256);
       int st;
-      // hi/lo pairs: 256 x 256 only when op(A) is k-contiguous (the other two layouts exceed 256 registers there)
-      if (split == 3) st = (big && code >= 2) ? launch_layout<3, 256>(sub, code, s) : launch_layout<3, 128>(sub, code, s);
+      if (split == 3) st = big ? launch_layout<3, 256>(sub, code, s) : launch_layout<3, 128>(sub, code, s);
       else st = big ? launch_layout<1, 256>(sub, code, s) : launch_layout<1, 128>(sub, code, s);
       if (st != CRW_OK) return st;
     }
