@@ -611,6 +611,25 @@ def test_propagate_with_cnn_at_32x32_patches_vs_oracle(hip):
     assert pred.shape == (N, T) and agree >= 0.99, agree
 
 
+def test_shared_column_encoding_two_radargrams(hip):
+    """forward_columns with B = 2 radargrams and stride 3: loss == item-wise loss on the same 2 x 3 windows."""
+    import model as crw_model
+    import encoder as crw_encoder
+    import dataset as crw_dataset
+    T = 6
+    cols, items = [], []
+    for seed in (21, 22):
+        ds = crw_dataset.RGDataset.synthetic(64, 16 * 13, T, (16, 16), (8, 0), seed=seed)  # 13 columns -> windows at 0, 3, 6
+        cols.append(ds.columns())
+        items += [ds[i] for i in range(0, len(ds), 3)]
+    torch.manual_seed(3)
+    net = crw_model.CRW(crw_encoder.CNN(False), 0.05, False).cuda()
+    l_cols, A = net.forward_columns(torch.stack(cols).cuda(), T, 3)
+    l_items, _ = net(torch.stack(items).cuda())
+    assert A.shape[:2] == (2, 12) and len(items) == 6
+    assert abs(l_cols.item() - l_items.item()) <= 1e-6 * abs(l_items.item())
+
+
 def test_no_cpu_fallback(hip):
     import model as crw_model
     with pytest.raises(RuntimeError):
