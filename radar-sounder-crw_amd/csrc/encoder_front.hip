@@ -57,6 +57,13 @@ struct FrontArgs {
 };
 
 // ---- shared forward pieces ----------------------------------------------------------------------
+// c1r / c2r pixel index.  PAD = true (backward kernel): the maps carry a one-pixel border (never read by a valid
+// pooling window, never initialised), so the pooling backward reads a pixel's 3x3 neighbourhood at constant offsets.
+template <bool PAD>
+__device__ inline int c1_idx(int y, int x) { return PAD ? (y + 1) * (C1W + 2) + x + 1 : y * C1W + x; }
+template <bool PAD>
+__device__ inline int c2_idx(int y, int x) { return PAD ? (y + 1) * (C2W + 2) + x + 1 : y * C2W + x; }
+
 struct FwdLds {
   float *xs;      // [cin][18][18]
   float *w1;      // [cin][25][8 co] + b1[8]
@@ -68,6 +75,7 @@ struct FwdLds {
 
 // conv1 + bias + ReLU: thread = (output pixel, 4 of the 8 channels): 392 threads.  The LDS weights are laid out
 // [ci][tap][8 co] so the four weights of a tap are one 16-byte broadcast read: 2 LDS reads per 4 FMAs.
+template <bool PAD>
 __device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
   if (tid < C1N * 2) {
     const int pix = tid >> 1, c0 = 4 * (tid & 1);
@@ -86,17 +94,18 @@ __device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
         acc.w = fmaf(v, wv.w, acc.w);
       }
     }
-    *reinterpret_cast<float4 *>(L.c1r + pix * 8 + c0) = float4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+    *reinterpret_cast<float4 *>(L.c1r + c1_idx<PAD>(y, xx) * 8 + c0) = float4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
   }
 }
 
 // maxpool 2x2/1 of c1r -> a1 planes (interior of the 15x15 padded image)
-template <int SPLIT>
+template <int SPLIT, bool PAD>
 __device__ inline void pool1(const FwdLds &L, int tid) {
+  constexpr int ROW = (PAD ? C1W + 2 : C1W) * 8;
   for (int e = tid; e < A1W * A1W * 8; e += NTH) {
     const int c = e & 7, p = e >> 3, y = p / A1W, x = p % A1W;
-    const float *s = L.c1r + (y * C1W + x) * 8 + c;
-    const float v = fmaxf(fmaxf(s[0], s[8]), fmaxf(s[C1W * 8], s[C1W * 8 + 8]));
+    const float *s = L.c1r + c1_idx<PAD>(y, x) * 8 + c;
+    const float v = fmaxf(fmaxf(s[0], s[8]), fmaxf(s[ROW], s[ROW + 8]));
     const uint16_t h = f2bf(v);
     const int o = ((y + 1) * A1PW + x + 1) * 16 + 2 * c;
     *reinterpret_cast<uint16_t *>(L.a1h + o) = h;
@@ -105,7 +114,7 @@ __device__ inline void pool1(const FwdLds &L, int tid) {
 }
 
 // conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  16 output tiles (8 row x 2 column), one per wave.
-template <int SPLIT>
+template <int SPLIT, bool PAD>
 __device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bias = b2[16 (wave & 1) + lane % 16]
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   const int mt = wave >> 1, j = wave & 1;
@@ -134,21 +143,21 @@ __device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bi
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 16 * mt + 4 * g + r;
-    if (i < C2N) L.c2r[i * 32 + co] = fmaxf(acc[r] + b, 0.f);
+    if (i < C2N) L.c2r[c2_idx<PAD>(i / C2W, i % C2W) * 32 + co] = fmaxf(acc[r] + b, 0.f);
   }
 }
 
-__device__ inline FwdLds carve_fwd(char *&p, int cin) {
+__device__ inline FwdLds carve_fwd(char *&p, int cin, bool pad = false) {  // pad: bordered c1r / c2r (backward kernel)
   FwdLds L;
   auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
   L.xs = (float *)take(sizeof(float) * cin * XPW * XPW);
   L.w1 = (float *)take(sizeof(float) * (8 * cin * 25 + 8));
-  L.c1r = (float *)take(sizeof(float) * C1N * 8);
+  L.c1r = (float *)take(sizeof(float) * (pad ? (C1W + 2) * (C1W + 2) : C1N) * 8);
   L.a1h = take(A1PW * A1PW * 16);
   L.a1l = take(A1PW * A1PW * 16);
   L.w2h = take(KS2 * 32 * 32 * 2);
   L.w2l = take(KS2 * 32 * 32 * 2);
-  L.c2r = (float *)take(sizeof(float) * C2N * 32);
+  L.c2r = (float *)take(sizeof(float) * (pad ? (C2W + 2) * (C2W + 2) : C2N) * 32);
   return L;
 }
 
@@ -186,11 +195,11 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
     if (tid < nx) L.xs[((tid >> 8) * XPW + ((tid >> 4) & 15) + 1) * XPW + (tid & 15) + 1] = x_r;
     if (pt + (int)gridDim.x < a.P) x_r = a.x[(long)(pt + gridDim.x) * nx + min(tid, nx - 1)];
     lds_barrier();
-    conv1_relu(L, a.cin, tid);
+    conv1_relu<false>(L, a.cin, tid);
     lds_barrier();
-    pool1<SPLIT>(L, tid);
+    pool1<SPLIT, false>(L, tid);
     lds_barrier();
-    conv2_relu<SPLIT>(L, b2r, tid);
+    conv2_relu<SPLIT, false>(L, b2r, tid);
     lds_barrier();
     // maxpool 2x2/1 -> output planes [100][32]
     for (int e = tid; e < ON * 32; e += NTH) {
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
       if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + q * 16 + 2 * c) = f2bf(v - bf2f(h));
     }
     lds_barrier();
-    conv2_relu<SPLIT>(L, b2r, tid);
+    conv2_relu<SPLIT, false>(L, b2r, tid);
     lds_barrier();
     for (int e = tid; e < ON * 32; e += NTH) {  // maxpool 2x2/1 -> the in-map part of the output tile
       const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
@@ -372,26 +381,26 @@ __device__ inline int argmax4(float a, float b, float c, float d) {
 // Gradient reaching pixel (y, x) of a W x W map through a 2x2/stride-1 max-pool whose (W-1) x (W-1) output has
 // gradient dout: the up to four windows containing the pixel route their gradient to it iff it is the FIRST
 // maximum of the window in row-major order (torch's tie rule, = argmax4 above).  The four windows only involve
-// the pixel's 3x3 neighbourhood, read once (8 LDS reads instead of 16).  in/dout: channel-interleaved with CS floats
-// per pixel; the caller has checked in[pixel] > 0 (ReLU).
+// the pixel's 3x3 neighbourhood, read once (8 LDS reads instead of 16).  in: bordered map (c1_idx / c2_idx with
+// PAD), dout: [W-1][W-1], both channel-interleaved with CS floats per pixel; the caller has checked in[pixel] > 0 (ReLU).
 template <int W, int CS>
 __device__ inline float pool_bwd_pixel(const float *__restrict__ in, const float *__restrict__ dout, int y, int x, int c,
                                        float mine) {
+  // `in` is the bordered map [(W+2)][(W+2)][CS]: the 8 neighbours sit at constant offsets from the pixel
+  const float *ctr = in + ((y + 1) * (W + 2) + x + 1) * CS + c;
   float nb[3][3];
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int yy = min(max(y + dy - 1, 0), W - 1), xx = min(max(x + dx - 1, 0), W - 1);  // clamped: only used by valid windows
-      nb[dy][dx] = (dy == 1 && dx == 1) ? mine : in[(yy * W + xx) * CS + c];
-    }
+    for (int dx = 0; dx < 3; ++dx)
+      nb[dy][dx] = (dy == 1 && dx == 1) ? mine : ctr[((dy - 1) * (W + 2) + (dx - 1)) * CS];
   float gsum = 0.f;
 #pragma unroll
   for (int dyw = 0; dyw < 2; ++dyw)
 #pragma unroll
     for (int dxw = 0; dxw < 2; ++dxw) {
       const int wy = y - dyw, wx = x - dxw;
-      if (wy >= 0 && wy < W - 1 && wx >= 0 && wx < W - 1) {
+      if (wy >= 0 && wy < W - 1 && wx >= 0 && wx < W - 1) {  // border values are only ever read for invalid windows
         const int k = dyw * 2 + dxw;  // this pixel's position in the window
         bool win = true;
 #pragma unroll
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *p = lds;
   const int cin = a.f.cin;
-  const FwdLds L = carve_fwd(p, cin);
+  const FwdLds L = carve_fwd(p, cin, true);
   auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
   char *wbh = take(25 * 8 * 32 * 2), *wbl = take(25 * 8 * 32 * 2);
   char *d2h = take(2 * D2HALF), *d2l = take(2 * D2HALF);  // dC2 (masked), padded by 4, [co half][pix][16] bf16
@@ -479,20 +488,20 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     if (pt + 1 < p_end) fetch(pt + 1);
     lds_barrier();
     FRONT_STAMP(0)
-    conv1_relu(L, cin, tid);
+    conv1_relu<true>(L, cin, tid);
     lds_barrier();
     FRONT_STAMP(1)
-    pool1<SPLIT>(L, tid);
+    pool1<SPLIT, true>(L, tid);
     lds_barrier();
     FRONT_STAMP(2)
-    conv2_relu<SPLIT>(L, b2r, tid);
+    conv2_relu<SPLIT, true>(L, b2r, tid);
     lds_barrier();
     FRONT_STAMP(3)
 
     // ---- pool2 + ReLU2 backward: dC2[pix][co] (masked) -> padded bf16 planes, bias gradient ------
     for (int e = tid; e < C2N * 32; e += NTH) {
       const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
-      const float mine = L.c2r[e];
+      const float mine = L.c2r[c2_idx<true>(y, x) * 32 + co];
       const float gsum = mine > 0.f ? pool_bwd_pixel<C2W, 32>(L.c2r, dyb, y, x, co, mine) : 0.f;
       db2 += gsum;  // thread t always meets channel t & 31
       const uint16_t h = f2bf(gsum);
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     // ---- pool1 + ReLU1 backward -> dC1 [196][8]; then the d2 planes' interior is cleared for the next patch ----
     for (int e = tid; e < C1N * 8; e += NTH) {
       const int co = e & 7, pix = e >> 3, y = pix / C1W, x = pix % C1W;
-      const float mine = L.c1r[e];
+      const float mine = L.c1r[c1_idx<true>(y, x) * 8 + co];
       const float gsum = mine > 0.f ? pool_bwd_pixel<C1W, 8>(L.c1r, dA1, y, x, co, mine) : 0.f;
       dC1[e] = gsum;
       db1 += gsum;  // thread t always meets channel t & 7
@@ -675,14 +684,15 @@ __global__ __launch_bounds__(256) void front_slice_sum_kernel(const float *__res
   if (lane == 0) out[e] = s;
 }
 
-size_t fwd_lds_bytes(int cin) {
+size_t fwd_lds_bytes(int cin, bool pad = false) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return r(4 * cin * XPW * XPW) + r(4 * (8 * cin * 25 + 8)) + r(4 * C1N * 8) + 2 * r(A1PW * A1PW * 16) +
-         2 * r(KS2 * 32 * 32 * 2) + r(4 * C2N * 32);
+  const size_t c1 = pad ? (C1W + 2) * (C1W + 2) : C1N, c2 = pad ? (C2W + 2) * (C2W + 2) : C2N;
+  return r(4 * cin * XPW * XPW) + r(4 * (8 * cin * 25 + 8)) + r(4 * c1 * 8) + 2 * r(A1PW * A1PW * 16) +
+         2 * r(KS2 * 32 * 32 * 2) + r(4 * c2 * 32);
 }
 size_t bwd_lds_bytes(int cin) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return fwd_lds_bytes(cin) + 2 * r(25 * 8 * 32 * 2) + 2 * r(2 * D2HALF) + r(4 * ON * 32);
+  return fwd_lds_bytes(cin, true) + 2 * r(25 * 8 * 32 * 2) + 2 * r(2 * D2HALF) + r(4 * ON * 32);
 }
 int front_slices(int P) { return P < 256 ? P : 256; }  // one 144 KB workgroup per CU
 
