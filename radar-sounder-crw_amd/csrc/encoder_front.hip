@@ -69,7 +69,7 @@ struct FwdLds {
   float *w1;      // [cin][25][8 co] + b1[8]
   float *c1r;     // [196][8]
   char *a1h, *a1l;  // [225][8] bf16 (16 B per pixel)
-  char *w2h, *w2l;  // [7][32][32] bf16
+  char *w2h, *w2l;  // [7][2 k halves][32 co][16 k] bf16 (w2_lds_chunk)
   float *c2r;     // [121][32]
 };
 
@@ -113,6 +113,14 @@ __device__ inline void pool1(const FwdLds &L, int tid) {
   }
 }
 
+// conv2 forward weights in LDS: the packed global planes [7 k-steps][32 co][4 chunks of 8 k] are stored as
+// [7][2 k halves][32 co][2 chunks] (32-byte rows): on 64-byte rows the ds_read_b128 lane groups of a B-fragment read
+// collide 2-way, on the split layout they cover all 64 banks (same trick as the d2 planes).
+__device__ inline int w2_lds_chunk(int e) {  // 16-byte chunk index: global -> LDS
+  const int ch = e & 3, co = (e >> 2) & 31, s = e >> 7;
+  return ((s * 2 + (ch >> 1)) * 32 + co) * 2 + (ch & 1);
+}
+
 // conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  16 output tiles (8 row x 2 column), one per wave.
 template <int SPLIT, bool PAD>
 __device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bias = b2[16 (wave & 1) + lane % 16]
@@ -127,7 +135,7 @@ __device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bi
     int tap = 4 * s + g;
     if (tap > 24) tap = 24;  // k-steps beyond tap 24 carry zero weights
     const int toff = (tap / 5) * A1PW + (tap % 5);
-    const int o = ((s * 32 + 16 * j + r16) * 32 + 8 * g) * 2;
+    const int o = (((s * 2 + (g >> 1)) * 32 + 16 * j + r16) * 2 + (g & 1)) * 16;
     const bf8 bh = *reinterpret_cast<const bf8 *>(L.w2h + o);
     const bf8 ah = *reinterpret_cast<const bf8 *>(L.a1h + (base + toff) * 16);
     if (SPLIT == 3) {
@@ -174,8 +182,9 @@ __device__ inline void stage_constants(const FwdLds &L, const FrontArgs &a, int 
     reinterpret_cast<uint32_t *>(L.a1l)[e] = 0;
   }
   for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
-    reinterpret_cast<uint4 *>(L.w2h)[e] = reinterpret_cast<const uint4 *>(a.w2h)[e];
-    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[e] = reinterpret_cast<const uint4 *>(a.w2l)[e];
+    const int d = w2_lds_chunk(e);
+    reinterpret_cast<uint4 *>(L.w2h)[d] = reinterpret_cast<const uint4 *>(a.w2h)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[d] = reinterpret_cast<const uint4 *>(a.w2l)[e];
   }
 }
 
@@ -247,8 +256,9 @@ __global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
   }
   if (tid < 8) L.w1[8 * cin * 25 + tid] = a.f.b1[tid];
   for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
-    reinterpret_cast<uint4 *>(L.w2h)[e] = reinterpret_cast<const uint4 *>(a.f.w2h)[e];
-    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[e] = reinterpret_cast<const uint4 *>(a.f.w2l)[e];
+    const int d = w2_lds_chunk(e);
+    reinterpret_cast<uint4 *>(L.w2h)[d] = reinterpret_cast<const uint4 *>(a.f.w2h)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[d] = reinterpret_cast<const uint4 *>(a.f.w2l)[e];
   }
   const float b2r = a.f.b2[16 * ((tid >> 6) & 1) + (tid & 15)];
   const int H = a.H, W = a.W, Ho = H - 6, Wo = W - 6, ntile = a.tiles_x * a.tiles_y;
@@ -382,35 +392,41 @@ __device__ inline int argmax4(float a, float b, float c, float d) {
 // gradient dout: the up to four windows containing the pixel route their gradient to it iff it is the FIRST
 // maximum of the window in row-major order (torch's tie rule, = argmax4 above).  The four windows only involve
 // the pixel's 3x3 neighbourhood, read once (8 LDS reads instead of 16).  in: bordered map (c1_idx / c2_idx with
-// PAD), dout: [W-1][W-1], both channel-interleaved with CS floats per pixel; the caller has checked in[pixel] > 0 (ReLU).
+// PAD), dout: [W-1][W-1], both channel-interleaved with CS floats per pixel; the ReLU gate (in[pixel] > 0) is applied here.
 template <int W, int CS>
-__device__ inline float pool_bwd_pixel(const float *__restrict__ in, const float *__restrict__ dout, int y, int x, int c,
-                                       float mine) {
-  // `in` is the bordered map [(W+2)][(W+2)][CS]: the 8 neighbours sit at constant offsets from the pixel
+__device__ inline float pool_bwd_pixel(const float *__restrict__ in, const float *__restrict__ dout, int y, int x, int c) {
+  // `in` is the bordered map [(W+2)][(W+2)][CS]: the 8 neighbours sit at constant offsets from the pixel.  All 13
+  // LDS reads (pixel, neighbours, the 4 window gradients at clamped addresses) are unconditional and independent,
+  // so they are in flight together; branches around single loads made each of them a separate round trip.
   const float *ctr = in + ((y + 1) * (W + 2) + x + 1) * CS + c;
-  float nb[3][3];
+  float nb[3][3], dv[2][2];
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-      nb[dy][dx] = (dy == 1 && dx == 1) ? mine : ctr[((dy - 1) * (W + 2) + (dx - 1)) * CS];
+    for (int dx = 0; dx < 3; ++dx) nb[dy][dx] = ctr[((dy - 1) * (W + 2) + (dx - 1)) * CS];
+#pragma unroll
+  for (int dyw = 0; dyw < 2; ++dyw)
+#pragma unroll
+    for (int dxw = 0; dxw < 2; ++dxw) {
+      const int wy = min(max(y - dyw, 0), W - 2), wx = min(max(x - dxw, 0), W - 2);
+      dv[dyw][dxw] = dout[(wy * (W - 1) + wx) * CS + c];
+    }
+  const float mine = nb[1][1];
   float gsum = 0.f;
 #pragma unroll
   for (int dyw = 0; dyw < 2; ++dyw)
 #pragma unroll
     for (int dxw = 0; dxw < 2; ++dxw) {
       const int wy = y - dyw, wx = x - dxw;
-      if (wy >= 0 && wy < W - 1 && wx >= 0 && wx < W - 1) {  // border values are only ever read for invalid windows
-        const int k = dyw * 2 + dxw;  // this pixel's position in the window
-        bool win = true;
+      bool win = mine > 0.f && wy >= 0 && wy < W - 1 && wx >= 0 && wx < W - 1;  // ReLU; border values only meet invalid windows
+      const int k = dyw * 2 + dxw;  // this pixel's position in the window
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j != k) {
-            const float v = nb[1 - dyw + (j >> 1)][1 - dxw + (j & 1)];
-            win = win && (j < k ? mine > v : mine >= v);
-          }
-        if (win) gsum += dout[(wy * (W - 1) + wx) * CS + c];
-      }
+      for (int j = 0; j < 4; ++j)
+        if (j != k) {
+          const float v = nb[1 - dyw + (j >> 1)][1 - dxw + (j & 1)];
+          win = win && (j < k ? mine > v : mine >= v);
+        }
+      gsum += win ? dv[dyw][dxw] : 0.f;
     }
   return gsum;
 }
@@ -448,8 +464,9 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   f32x4 wacc[2];
   wacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
   wacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float db2 = 0.f, dw1 = 0.f, db1 = 0.f;
-  const int nout = 8 * cin * 25, npart = NTH / nout;  // conv1 weight gradient: outputs x pixel parts (200 x 5 | 400 x 2)
+  float db2 = 0.f, db1 = 0.f, dw1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  // conv1 weight gradient: outputs; threads (co, ci, ty, row part), each part = cin pixel rows -> 560 threads either way
+  const int nout = 8 * cin * 25, nrp = C1W / cin, nrowthr = 8 * cin * 5 * nrp;
 
   const uint32_t d2h_a = (uint32_t)(uintptr_t)(lds_cp)d2h, d2l_a = (uint32_t)(uintptr_t)(lds_cp)d2l;
   const uint32_t a1h_a = (uint32_t)(uintptr_t)(lds_cp)L.a1h, a1l_a = (uint32_t)(uintptr_t)(lds_cp)L.a1l;
@@ -501,8 +518,7 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     // ---- pool2 + ReLU2 backward: dC2[pix][co] (masked) -> padded bf16 planes, bias gradient ------
     for (int e = tid; e < C2N * 32; e += NTH) {
       const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
-      const float mine = L.c2r[c2_idx<true>(y, x) * 32 + co];
-      const float gsum = mine > 0.f ? pool_bwd_pixel<C2W, 32>(L.c2r, dyb, y, x, co, mine) : 0.f;
+      const float gsum = pool_bwd_pixel<C2W, 32>(L.c2r, dyb, y, x, co);
       db2 += gsum;  // thread t always meets channel t & 31
       const uint16_t h = f2bf(gsum);
       const int o = (co >> 4) * D2HALF + ((y + 4) * D2PW + x + 4) * 32 + 2 * (co & 15);
@@ -601,28 +617,34 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     // ---- pool1 + ReLU1 backward -> dC1 [196][8]; then the d2 planes' interior is cleared for the next patch ----
     for (int e = tid; e < C1N * 8; e += NTH) {
       const int co = e & 7, pix = e >> 3, y = pix / C1W, x = pix % C1W;
-      const float mine = L.c1r[c1_idx<true>(y, x) * 8 + co];
-      const float gsum = mine > 0.f ? pool_bwd_pixel<C1W, 8>(L.c1r, dA1, y, x, co, mine) : 0.f;
-      dC1[e] = gsum;
-      db1 += gsum;  // thread t always meets channel t & 7
+      const float gsum = pool_bwd_pixel<C1W, 8>(L.c1r, dA1, y, x, co);
+      dC1[co * C1N + pix] = gsum;  // channel-major: the weight-gradient threads read whole pixel rows
+      db1 += gsum;                 // thread t always meets channel t & 7
     }
     lds_barrier();
     FRONT_STAMP(7)
 
-    // ---- conv1 weight gradient (VALU): thread (o, part) adds the pixel rows part, part + NPART, ... of output
-    // o = dW1[co][ci][tap] (whole rows: every LDS address is a base + immediate, the phase is bound by VALU
-    // issue otherwise); the NPART partial sums of an output meet at the very end of the kernel ----
-    if (tid < nout * npart) {
-      const int o = tid % nout, part = tid / nout;
-      const int tap = o % 25, ci = (o / 25) % cin, co = o / (25 * cin);
-      const float *xs = L.xs + (ci * XPW + tap / 5) * XPW + tap % 5;
-      float s = 0.f;
-      for (int y = part; y < C1W; y += npart) {
-        const float *dr = dC1 + y * C1W * 8 + co, *xr = xs + y * XPW;
+    // ---- conv1 weight gradient (VALU): thread = (co, ci, tap row ty, pixel row y).  It reads its 14 dC1 values and the
+    // 18 input values of the shifted row once and forms the 5 taps of that row from registers (32 LDS reads per 70
+    // FMAs; one output per thread needed 2 reads per FMA and was LDS-bound).  Lanes differ in y: strides 14 and 18
+    // floats are conflict-free.  The 14 row sums of an output meet at the very end of the kernel ----
+    if (tid < nrowthr) {
+      const int rp = tid % nrp, q = tid / nrp, ty = q % 5, ci = (q / 5) % cin, co = q / (5 * cin);
+      for (int y = rp; y < C1W; y += nrp) {
+        const float *dr = dC1 + co * C1N + y * C1W, *xr = L.xs + (ci * XPW + y + ty) * XPW;
+        float dv[C1W], xv[XPW];
 #pragma unroll
-        for (int x = 0; x < C1W; ++x) s = fmaf(dr[x * 8], xr[x], s);
+        for (int x = 0; x < C1W; ++x) dv[x] = dr[x];
+#pragma unroll
+        for (int x = 0; x < XPW; ++x) xv[x] = xr[x];
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+          float s1 = 0.f;
+#pragma unroll
+          for (int x = 0; x < C1W; ++x) s1 = fmaf(dv[x], xv[x + tx], s1);
+          dw1[tx] += s1;
+        }
       }
-      dw1 += s;
     }
     lds_barrier();  // next patch may overwrite xs / dyb
     FRONT_STAMP(8)
@@ -655,11 +677,14 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     out[32 * 8 * 25 + tid] = s;
   }
   __syncthreads();
-  red[tid] = dw1;
+  if (tid < nrowthr)
+#pragma unroll
+    for (int tx = 0; tx < 5; ++tx) red[tid * 5 + tx] = dw1[tx];  // [(co, ci, ty)][row part][tx]
   __syncthreads();
-  if (tid < nout) {
+  if (tid < nout) {  // output o = ((co * cin + ci) * 5 + ty) * 5 + tx: add its row parts in a fixed order
+    const int q = tid / 5, tx = tid % 5;
     float s = 0.f;
-    for (int k = 0; k < npart; ++k) s += red[tid + nout * k];
+    for (int y = 0; y < nrp; ++y) s += red[(q * nrp + y) * 5 + tx];
     out[32 * 8 * 25 + 32 + tid] = s;
   }
   __syncthreads();
