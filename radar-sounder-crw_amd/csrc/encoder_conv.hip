@@ -191,7 +191,7 @@ struct ConvArgs {
 // zeros outside it, only in-map output pixels are stored, `gap` receives per-tile SUMS (forward only).
 template <int SPLIT, int CIN, int COUT, int MODE, int NW, bool MAP = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
-  constexpr int PPW = 1, NT = NW * 64;
+  constexpr int NT = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
   // LDS row strides of the input image / the output staging and byte offset of the lo plane.  MAP windows carry real
@@ -286,13 +286,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
     if (SPLIT == 3) l = *reinterpret_cast<const bf8 *>(p + PLANE);
   };
 
-  f32x4 acc[PPW][MTW][NTW];
+  f32x4 acc[MTW][NTW];
 #pragma unroll
-  for (int q = 0; q < PPW; ++q)
+  for (int k = 0; k < MTW; ++k)
 #pragma unroll
-    for (int k = 0; k < MTW; ++k)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[q][k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int co_w = wn * (16 * NTW);  // first output channel of this wave
   auto load_b = [&](int step, bf8 (&bh)[NTW], bf8 (&bl)[NTW]) {
@@ -340,10 +338,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           if (SPLIT == 3) {
-            acc[0][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k], bhc[j], acc[0][k][j], 0, 0, 0);
-            acc[0][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], blc[j], acc[0][k][j], 0, 0, 0);
+            acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k], bhc[j], acc[k][j], 0, 0, 0);
+            acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], blc[j], acc[k][j], 0, 0, 0);
           }
-          acc[0][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], bhc[j], acc[0][k][j], 0, 0, 0);
+          acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], bhc[j], acc[k][j], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   if (TAIL >= 4) do_step(integral_constant<bool, TAIL == 4>{}, step + 3, bh3, bl3, bh2, bl2);
 
   // ---- epilogue ----------------------------------------------------------------------------------
-  // C/D map: acc[0][k][j][r] = out[patch p0][pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
+  // C/D map: acc[k][j][r] = out[patch p0][pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
   float bias_r[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) bias_r[j] = (MODE == 0 && a.bias) ? a.bias[co_w + 16 * j + r16] : 0.f;
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
           const int i = 16 * (wm + WM * k) + 4 * g + r;
           if (i < NPIX) {  // also false for the tiles a wave does not own (wm + WM k >= 7)
             const int pp = interior_pp(i);
-            float v = acc[0][k][j][r];
+            float v = acc[k][j][r];
             if (MODE == 0) {
               v = fmaxf(v + bias_r[j], 0.f);
               if (!MAP || (ty0 + i / IMG_W < a.mh && tx0 + i % IMG_W < a.mw)) gsum[j] += v;
