@@ -51,6 +51,9 @@ def get_args_parser():
     p.add_argument('--steps', default=0, type=int, help='stop after this many steps (0 = full epochs)')
     p.add_argument('--shared_encode', action='store_true',
                    help='batches of consecutive overlapping items share one encoder pass (needs --dataset_full)')
+    p.add_argument('--host_data', action='store_true',
+                   help='keep the radargram in host memory and feed items through a DataLoader like the reference '
+                        '(default: the radargram lives on the GPU and items are cut there, no per-step H2D copy)')
     p.add_argument('--save', default='', help='checkpoint path for encoder.state_dict() (default: '
                                               '<output_folder>/models/<output_name>.pt)')
     return p
@@ -76,6 +79,11 @@ def main(args):
     if args.shared_encode and not hasattr(dataset, 'columns'):
         raise SystemExit('--shared_encode needs the overlapping dataset (--dataset_full True)')
 
+    base = dataset.dataset if isinstance(dataset, Subset) else dataset
+    if not args.host_data:
+        # the item cut is a strided view of the radargram (src/dataset.py:19-39): with the radargram resident in
+        # HBM a batch is one gather kernel instead of a CPU unfold + 16 MB host-to-device copy per step
+        base.T = base.T.to(device)
     optimizer = Adam(model.parameters(), lr=args.lr, fused=True)  # one kernel for all parameters (same update rule)
     bucket = crw_dist.FlatGradBucket(model.parameters())
     model.train(True)
@@ -92,8 +100,11 @@ def main(args):
             nb = len(dataset) // args.batch_size
             loader = (dataset.columns(b * args.batch_size + rank * per_rank, per_rank + args.seq_length - 1)[None]
                       for b in torch.randperm(nb, generator=g).tolist())
-        else:
+        elif args.host_data:
             loader = DataLoader(Subset(dataset, mine), batch_size=per_rank, shuffle=False)
+        else:
+            loader = (torch.stack([dataset[i] for i in mine[b:b + per_rank]])
+                      for b in range(0, len(mine) - per_rank + 1, per_rank))
         loss_epoch = []
         for seq in loader:
             seq = seq.to(device, non_blocking=True)
