@@ -397,7 +397,7 @@ def main():
         enc.hip_convs = None if args.convs == "torch" else args.convs
     net = crw_model.CRW(enc, TAU, False).to(device)
     net.train(True)
-    bucket = crw_dist.FlatGradBucket(net.parameters())
+    bucket = crw_dist.FlatGradBucket(net.parameters(), lazy=True)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     seq = make_batch(rank, device)
     B, T, N = seq.shape[:3]

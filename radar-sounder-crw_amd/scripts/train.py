@@ -85,7 +85,7 @@ def main(args):
         # HBM a batch is one gather kernel instead of a CPU unfold + 16 MB host-to-device copy per step
         base.T = base.T.to(device)
     optimizer = Adam(model.parameters(), lr=args.lr, fused=True)  # one kernel for all parameters (same update rule)
-    bucket = crw_dist.FlatGradBucket(model.parameters())
+    bucket = crw_dist.FlatGradBucket(model.parameters(), lazy=True)
     model.train(True)
     loss_tot, nsteps = [], 0
     for epoch in range(args.epochs):

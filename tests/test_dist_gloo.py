@@ -76,3 +76,23 @@ def test_shard_indices_and_bucket_views():
     assert lin.weight.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
     assert lin.weight.grad.abs().sum() == 0
+
+
+def test_lazy_bucket_gathers_fresh_gradients():
+    """lazy=True: zero() drops the gradients, backward produces fresh tensors (no accumulation kernels),
+    all_reduce_mean() gathers them into the flat buffer and re-binds p.grad to its views; a second step starts clean."""
+    import dist as crw_dist
+    lin = torch.nn.Linear(3, 2)
+    b = crw_dist.FlatGradBucket(lin.parameters(), lazy=True)
+    for scale in (1.0, 3.0):
+        b.zero()
+        assert lin.weight.grad is None and lin.bias.grad is None
+        (lin(torch.ones(1, 3)).sum() * scale).backward()
+        assert lin.weight.grad.data_ptr() != b.flat.data_ptr()
+        flat = b.all_reduce_mean()
+        assert flat[:6].tolist() == [scale] * 6 and flat[6:].tolist() == [scale] * 2
+        assert lin.weight.grad.data_ptr() == b.flat.data_ptr() and torch.equal(lin.weight.grad, flat[:6].view(2, 3))
+    b.zero()
+    lin.weight.sum().backward()  # bias gets no gradient this time
+    flat = b.all_reduce_mean()
+    assert flat[:6].tolist() == [1.0] * 6 and flat[6:].tolist() == [0.0, 0.0]
