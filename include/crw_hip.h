@@ -108,6 +108,12 @@ int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, in
 int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream);
 
 /* building blocks exported for tests and the roofline bench --------------------------------- */
+/* Weight gradient of the CNN encoder's linear head (nn.Linear(128, 128), src/encoder.py:40,55; autograd of
+ * src/model.py:20): dw[o][i] = sum_p dy[p][o] x[p][i] as P/128 batched 128x128 fp32-MFMA products whose partial matrices
+ * are added in a fixed order (a library GEMM runs this M=N=128, K=P shape on 16 workgroups).  P % 128 == 0. */
+size_t crw_linear128_wgrad_ws_bytes(int P);
+int crw_linear128_wgrad(const float *dy, const float *x, float *dw, int P, void *ws, size_t ws_bytes, crw_stream_t stream);
+
 /* X [batch,n,n] (n multiple of 32, zero padded): C = op(A) * op(B) (+ C if beta), fp32 MFMA. */
 int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
                  int beta, crw_stream_t stream);

@@ -35,6 +35,8 @@ SIGNATURES = {
     "crw_labelprop_topk": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
+    "crw_linear128_wgrad_ws_bytes": (_c_sz, [_c_int]),
+    "crw_linear128_wgrad": (_c_int, [_p, _p, _p, _c_int, _p, _c_sz, _p]),
     "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
     "crw_enc_pack_weights": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
@@ -245,6 +247,17 @@ def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=
                                  _bf(yl, "yl"), _dev(yf, "yf") if f32 else None, _dev(gp, "gap") if gap else None,
                                  _dev(dgap, "dgap") if dgap is not None else None, _stream()), "crw_enc_conv3x3")
     return yh, yl, yf, gp
+
+
+def linear128_wgrad(dy, x):
+    """dw [128,128] = dy.T @ x for dy, x [P,128] with P % 128 == 0 (split over P, deterministic)."""
+    P = x.shape[0]
+    dw = torch.empty(128, 128, dtype=torch.float32, device=x.device)
+    nbytes = lib().crw_linear128_wgrad_ws_bytes(P)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _check(lib().crw_linear128_wgrad(_dev(dy.contiguous(), "dy"), _dev(x.contiguous(), "x"), _dev(dw, "dw"), P,
+                                     ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()), "crw_linear128_wgrad")
+    return dw
 
 
 def enc_pack_input_map(x, split):

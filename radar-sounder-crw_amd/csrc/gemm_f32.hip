@@ -263,7 +263,51 @@ int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s) {
   return check_launch();
 }
 
+// out[e] = sum_b part[b][e], fixed order (deterministic)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float *__restrict__ part, int nb, int n, float *__restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(b + u) * n + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < nb; ++b) s += part[(long)b * n + e];
+  out[e] = s;
+}
+
 }  // namespace crw
+
+// Weight gradient of the CNN encoder's linear head (nn.Linear(128, 128), src/encoder.py:40,55):
+//   dW[o][i] = sum_p dy[p][o] x[p][i]      (M = N = 128, K = P)
+// A library GEMM sees 16 output tiles and a K of P (hipBLASLt: 16 workgroups, ~100 us at P = 16128); here the sum over p
+// is split into P/128 batched 128 x 128 fp32-MFMA products dy_b^T x_b (every CU busy) whose partial matrices are added
+// in a fixed order.  P must be a multiple of 128; ws holds P/128 * 128 * 128 floats.
+extern "C" size_t crw_linear128_wgrad_ws_bytes(int P) { return P < 128 ? 0 : (size_t)(P / 128) * 128 * 128 * sizeof(float); }
+
+extern "C" int crw_linear128_wgrad(const float *dy, const float *x, float *dw, int P, void *ws, size_t ws_bytes,
+                                   crw_stream_t stream) {
+  crw::clear_stale_error();
+  if (!dy || !x || !dw || !ws || P < 128 || P % 128) return CRW_EINVAL;
+  if (ws_bytes < crw_linear128_wgrad_ws_bytes(P)) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  crw::GemmGroup g{};
+  g.nprob = 1;
+  g.n = 128;
+  g.batch = P / 128;
+  crw::GemmProb &p = g.p[0];
+  p.A = dy; p.B = x; p.C = static_cast<float *>(ws);
+  p.sA = p.sB = p.sC = 128L * 128;
+  p.ta = 1; p.tb = 0; p.beta = 0;
+  CRW_TRY(crw::launch_gemm_group_f32(g, s));
+  hipLaunchKernelGGL(crw::batch_sum_kernel, dim3(128 * 128 / 256), dim3(256), 0, s, static_cast<const float *>(ws), P / 128,
+                     128 * 128, dw);
+  return crw::check_launch();
+}
 
 extern "C" int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,
                             int beta, crw_stream_t stream) {

@@ -57,6 +57,24 @@ class _HipEncoder(torch.autograd.Function):
         ctx.saved = None
         return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
+class _HipLinear(torch.autograd.Function):
+    """The 128 -> 128 head.  Forward and dX are PyTorch matmuls; the weight gradient dW = dy^T x (M = N = 128, K = P)
+    runs on `crw_linear128_wgrad`: hipBLASLt gives that shape 16 workgroups (~100 us at P = 16128), the split over P
+    keeps every CU busy (~25 us) and adds the partial matrices in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return TF.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import crw_hip
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        return dy @ w, crw_hip.linear128_wgrad(dy, x), dy.sum(0)
+
+
 # (name, out_channels, kernel, followed by 2x2/stride-1 max-pool?)
 _CNN_STACK = (("1", 8, 5, True), ("2", 32, 5, True), ("3", 64, 3, False), ("4", 128, 3, False), ("5", 128, 3, False))
 
@@ -91,15 +109,20 @@ class CNN(nn.Module):
             gap = _HipEncoder.apply(x, c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[2].weight, c[2].bias,
                                     c[3].weight, c[3].bias, c[4].weight, c[4].bias,
                                     3 if self.hip_convs == "bf16x3" else 1)
-            return self.fc(gap)
+            return self._head(gap)
         if (self.hip_convs and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
                 and min(x.shape[-2:]) >= 7):
-            return self.fc(self._hip_inference_trunk(x))
+            return self._head(self._hip_inference_trunk(x))
         for name, _, _, pooled in _CNN_STACK:
             x = getattr(self, "relu" + name)(getattr(self, "conv" + name)(x))
             if pooled:
                 x = getattr(self, "pool" + name)(x)
         return self.fc(self.global_avg_pool(x).flatten(1))
+
+    def _head(self, gap):
+        if gap.shape[0] % 128 == 0 and gap.shape[0] >= 128 and self.fc.weight.shape == (128, 128) and self.fc.bias is not None:
+            return _HipLinear.apply(gap, self.fc.weight, self.fc.bias)
+        return self.fc(gap)
 
     def _hip_inference_trunk(self, x):
         """Inference (no autograd) at patch sizes other than 16x16 -- e.g. the 32x32 patches of BASELINE config 5:

@@ -630,6 +630,39 @@ def test_shared_column_encoding_two_radargrams(hip):
     assert abs(l_cols.item() - l_items.item()) <= 1e-6 * abs(l_items.item())
 
 
+def test_linear_head_kernel_and_model_path(hip):
+    """crw_linear128_wgrad (weight gradient of the 128 -> 128 head, split over the patches) against dy^T x in fp64, and the
+    model path that uses it (patch count a multiple of 128) against the same model on PyTorch's linear."""
+    import torch.nn.functional as TF
+    import model as crw_model
+    import encoder as crw_encoder
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(384, 128, generator=g).cuda()
+    w = (torch.randn(128, 128, generator=g) * 0.1).cuda()
+    dy = torch.randn(384, 128, generator=g).cuda()
+    ref = (dy.double().t() @ x.double()).float()
+    got = hip.linear128_wgrad(dy, x)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-4)
+    assert torch.equal(got, hip.linear128_wgrad(dy, x))  # fixed summation order
+    with pytest.raises(RuntimeError):
+        hip.linear128_wgrad(dy[:100], x[:100])
+    seq = torch.randn(1, 8, 16, 16, 16, generator=g).cuda()  # 128 patches
+    torch.manual_seed(2)
+    enc = crw_encoder.CNN(False)
+    net = crw_model.CRW(enc, 0.05, False).cuda()
+    res = []
+    for use_hip_head in (True, False):
+        net.zero_grad()
+        if not use_hip_head:
+            enc._head = enc.fc
+        loss, _ = net(seq)
+        loss.backward()
+        res.append((loss.item(), [p.grad.clone() for p in enc.parameters()]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
+    for a_, b_ in zip(res[0][1], res[1][1]):
+        torch.testing.assert_close(a_, b_, rtol=1e-3, atol=1e-5 * b_.abs().max().item() + 1e-9)
+
+
 def test_no_cpu_fallback(hip):
     import model as crw_model
     with pytest.raises(RuntimeError):
