@@ -41,6 +41,8 @@ def parse():
                          "bf16 = HIP kernels, plain bf16 operands; torch = PyTorch-ROCm (MIOpen) fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
+    ap.add_argument("--no-events", action="store_true",
+                    help="do not bracket the conv kernels of the timed steps with HIP events (A/B of their overhead)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared", "dense"],
                     help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
@@ -103,37 +105,6 @@ def walk_probe(B, T, N, iters=20):
     ms = e0.elapsed_time(e1) / iters
     Np = crw_hip.padded_nodes(N)
     return ms, 2.0 * Np ** 3 * (9 * (T - 3) + 3) * B
-
-
-def conv_probe(P, cin, cout, split, iters=10):
-    """HIP-event time of the three hand-written conv kernels of one encoder layer at the workload's
-    patch count (random planes; same launch geometry as inside the step)."""
-    import crw_hip
-    g = torch.Generator().manual_seed(5)
-    mk = lambda c: (torch.randn(P, 100, c, generator=g) * 0.5).cuda()
-    xf, dyf = mk(cin), mk(cout)
-    xh, dh = xf.bfloat16(), dyf.bfloat16()
-    xl = (xf - xh.float()).bfloat16() if split == 3 else None
-    dl = (dyf - dh.float()).bfloat16() if split == 3 else None
-    del xf, dyf
-    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
-    b = torch.zeros(cout, device="cuda")
-    fh, fl, bh, bl = crw_hip.enc_pack_weights(w, split)
-    calls = {"conv3x3_kernel fwd (bias+ReLU)": lambda: crw_hip.enc_conv3x3(0, split, xh, xl, fh, fl, cout, bias=b),
-             "conv3x3_kernel bwd-data (+ReLU mask)": lambda: crw_hip.enc_conv3x3(1, split, dh, dl, bh, bl, cin, mask=xh),
-             "conv3x3_wgrad_kernel": lambda: crw_hip.enc_wgrad(split, dh, dl, xh, xl)}
-    out = {}
-    for name, fn in calls.items():
-        for _ in range(2):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) / iters
-    return out
 
 
 def chain_probe_bf16(n, batch, split, iters=10):
@@ -417,6 +388,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    if rank == 0 and not args.no_events:
+        crw_hip.KERNEL_EVENTS = {}  # HIP events around every conv launch of the timed steps, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -446,25 +419,31 @@ def main():
                        "columns_per_step_per_gpu": cols_per_step, "parallelism": f"dp{world} (independent sequences)",
                        "chain": "fp32 MFMA 16x16x4, prefix form", "encoder_convs": args.convs, "loss": final_loss},
         }
+        kernels = []
+        if crw_hip.KERNEL_EVENTS:
+            # per-kernel durations measured live over the timed region (HIP events on the launch stream)
+            ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+            split = 3 if args.convs == "bf16x3" else 1
+            P = B * T * N
+            names = {"fwd": "conv3x3_kernel fwd (bias+ReLU)", "bwd": "conv3x3_kernel bwd-data (+ReLU mask)",
+                     "wgrad": "conv3x3_wgrad_kernel (+ slice sum)"}
+            for (kind, cin, cout), pairs in sorted(ev.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
+                kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
+                alg = 2.0 * P * 100 * cin * cout * 9  # algorithmic flops of one pass over one layer
+                pad = (10 * 32 / 3) / 100.0 if kind == "wgrad" else 112.0 / 100.0  # MFMA padding of the pixel dim: the weight
+                # gradient streams k-steps across patches (10 k-steps of 32 pixels per 3 patches), forward / backward-data
+                # run 7 row tiles of 16 per patch
+                kernels.append({"kernel": f"{names[kind]} cin={cin} cout={cout}", "bound": "mfma",
+                                "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
+                                "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                                "mfma_executed_tflops": alg * split * pad / (kms * 1e-3) / 1e12,
+                                "mfma_executed_frac": alg * split * pad / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                                "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // args.steps,
+                                "timed_launches": len(pairs),
+                                "note": "achieved = algorithmic (fp32-equivalent) flops / mean HIP-event time of this kernel's "
+                                        "launches INSIDE the timed steps (events recorded on the launch stream); "
+                                        f"split={split}: each product is {split} bf16 MFMAs"})
         if not args.no_probe:
-            kernels = []
-            if args.model == 0 and args.convs != "torch":
-                split = 3 if args.convs == "bf16x3" else 1
-                P = B * T * N
-                for cin, cout in ((128, 128), (64, 128), (32, 64)):
-                    alg = 2.0 * P * 100 * cin * cout * 9  # algorithmic flops of one pass over one layer
-                    for kname, kms in conv_probe(P, cin, cout, split).items():
-                        pad = (10 * 32 / 3) / 100.0 if "wgrad" in kname else 112.0 / 100.0  # MFMA padding of the pixel dim: the weight
-                        # gradient streams k-steps across patches (10 k-steps of 32 pixels per 3 patches), forward / backward-data
-                        # run 7 row tiles of 16 per patch
-                        kernels.append({"kernel": f"{kname} cin={cin} cout={cout}", "bound": "mfma",
-                                        "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
-                                        "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                                        "mfma_executed_tflops": alg * split * pad / (kms * 1e-3) / 1e12,
-                                        "mfma_executed_frac": alg * split * pad / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                                        "traffic": None, "launch_us": kms * 1e3, "launches_per_step": 1,
-                                        "note": "achieved = algorithmic (fp32-equivalent) flops / HIP-event time; "
-                                                f"split={split}: each product is {split} bf16 MFMAs"})
             Np = crw_hip.padded_nodes(N)
             pms, pfl = chain_probe(Np, B, 3)
             kernels.append({"kernel": "gemm_pad_f32_kernel<32,32> (batched cycle products, one launch)", "bound": "mfma",
@@ -472,36 +451,39 @@ def main():
                             "frac": pfl / (pms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], "traffic": None,
                             "launch_us": pms * 1e3, "shape": f"n={Np} batch={B}x3",
                             "note": "launch-latency bound at the reference-default node count"})
-            # HBM traffic from the committed PMC pass (profiles/r01_pmc_conv5.json; rocprofv3 cannot run inside bench)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))["kernels"]
-                for k in kernels:
-                    if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
-                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
-                               "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
-                               "conv3x3_kernel<3, 128, 128, 0, 8>")
-                        wr = pmc[key].get("hbm_write_bytes", pmc[key]["algorithmic_write_bytes"])
-                        k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + wr
-                        k["traffic_note"] = ("HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_conv5.json): reads = "
-                                             "2*1024*FETCH_SIZE (gfx950 correction), writes = 1024*WRITE_SIZE where measured, else the "
-                                             f"algorithmic slab bytes; read/algorithmic = {pmc[key]['read_over_algorithmic']}, "
-                                             f"L2 hit rate {pmc[key]['l2_hit_rate']}")
-                util = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")))["kernels"]
-                for k in kernels:
-                    if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
-                        key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
-                               "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
-                               "conv3x3_kernel<3, 128, 128, 0, 8>")
-                        k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
-                        k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
-                        k["pmc_note"] = ("committed PMC pass profiles/r01_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
-                                         "GRBM_GUI_ACTIVE/8) and the clock the chip held under this kernel (nominal 2.4 GHz)")
-            except Exception:
-                pass
+        # HBM traffic from the committed PMC pass (profiles/r01_pmc_conv5.json; rocprofv3 cannot run inside bench)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))["kernels"]
+            for k in kernels:
+                if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
+                    key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
+                           "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
+                           "conv3x3_kernel<3, 128, 128, 0, 8>")
+                    wr = pmc[key].get("hbm_write_bytes", pmc[key]["algorithmic_write_bytes"])
+                    k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + wr
+                    k["traffic_note"] = ("HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_conv5.json): reads = "
+                                         "2*1024*FETCH_SIZE (gfx950 correction), writes = 1024*WRITE_SIZE where measured, else the "
+                                         f"algorithmic slab bytes; read/algorithmic = {pmc[key]['read_over_algorithmic']}, "
+                                         f"L2 hit rate {pmc[key]['l2_hit_rate']}")
+            util = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_in_step.json")))["kernels"]
+            for k in kernels:
+                if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
+                    key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
+                           "conv3x3_kernel<3, 128, 128, 1, 8, false>" if "bwd-data" in k["kernel"] else
+                           "conv3x3_kernel<3, 128, 128, 0, 8, false>")
+                    k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
+                    k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
+                    k["pmc_note"] = ("committed PMC pass over this same command (profiles/r01_pmc_in_step.json): "
+                                     "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) and the clock the chip held "
+                                     "under this kernel inside the step (nominal 2.4 GHz)")
+        except Exception:
+            pass
+        if kernels:
             # the dominant kernel of the timed step = the hand-written kernel with the largest time per step
-            dom = max((k for k in kernels if "launches_per_step" in k), key=lambda k: k["launch_us"], default=kernels[-1])
-            out["roofline"] = dom
+            out["roofline"] = max((k for k in kernels if "launches_per_step" in k),
+                                  key=lambda k: k["launch_us"] * k["launches_per_step"], default=kernels[-1])
             out["roofline_kernels"] = kernels
+        if not args.no_probe:
             wms, wfl = walk_probe(B, T, N)
             out["walk_at_workload_shape"] = {"what": "affinity + dual softmax + chain + loss, fwd+bwd, features resident",
                                              "ms": wms, "chain_tflops": wfl / (wms * 1e-3) / 1e12,

@@ -92,6 +92,26 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# bench.py sets this to {} for its timed region: every conv / weight-gradient launch is then bracketed by two HIP events
+# recorded on the stream the kernel is launched on, {(kind, layer_cin, layer_cout): [(start, end), ...]}.  None = off.
+KERNEL_EVENTS = None
+
+
+def _ev_begin():
+    if KERNEL_EVENTS is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _ev_end(e0, key):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        KERNEL_EVENTS.setdefault(key, []).append((e0, e1))
+
+
 def padded_nodes(N, chain=CHAIN_F32):
     return lib().crw_padded_nodes(N, chain)
 
@@ -242,10 +262,12 @@ def enc_conv3x3(mode, split, xh, xl, wh, wl, cout, bias=None, mask=None, planes=
     yl = torch.empty_like(yh) if (planes and split == 3 and lo_plane) else None
     yf = torch.empty(P, 100, cout, dtype=torch.float32, device=dev) if f32 else None
     gp = torch.empty(P, cout, dtype=torch.float32, device=dev) if gap else None
+    ev = _ev_begin()
     _check(lib().crw_enc_conv3x3(mode, split, P, cin, cout, _bf(xh, "xh"), _bf(xl, "xl"), _bf(wh, "wh"), _bf(wl, "wl"),
                                  _dev(bias, "bias") if bias is not None else None, _bf(mask, "mask"), _bf(yh, "yh"),
                                  _bf(yl, "yl"), _dev(yf, "yf") if f32 else None, _dev(gp, "gap") if gap else None,
                                  _dev(dgap, "dgap") if dgap is not None else None, _stream()), "crw_enc_conv3x3")
+    _ev_end(ev, ("fwd", cin, cout) if mode == 0 else ("bwd", cout, cin))
     return yh, yl, yf, gp
 
 
@@ -302,10 +324,12 @@ def enc_wgrad(split, dyh, dyl, xh, xl, dgap=None):
     db = torch.empty(cout, dtype=torch.float32, device=xh.device)
     nbytes = lib().crw_enc_wgrad_ws_bytes(P, cin, cout, split)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xh.device)
+    ev = _ev_begin()
     _check(lib().crw_enc_conv3x3_wgrad(split, P, cin, cout, _bf(dyh, "dyh"), _bf(dyl, "dyl"), _bf(xh, "xh"),
                                        _bf(xl, "xl"), _dev(dgap, "dgap") if dgap is not None else None,
                                        _dev(dw, "dw"), _dev(db, "db"), ctypes.c_void_p(ws.data_ptr()),
                                        nbytes, _stream()), "crw_enc_conv3x3_wgrad")
+    _ev_end(ev, ("wgrad", cin, cout))
     return dw, db
 
 
