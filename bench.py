@@ -354,6 +354,8 @@ def main():
         args.no_probe = args.no_cpu_baseline = True
     import dist as crw_dist
     rank, world, local = crw_dist.init_from_env("nccl")
+    if world > 1:  # the stand-alone probes (chain at n = 4096, walk alone) are single-GPU figures; the per-kernel
+        args.no_probe = True  # roofline of the timed steps (HIP events) is reported at every N
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
