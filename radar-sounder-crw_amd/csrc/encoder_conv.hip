@@ -969,6 +969,9 @@ int launch_conv_map(const ConvArgs &a, hipStream_t s) {
 template <int SPLIT, int CIN, int COUT, int MODE>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   // measured (tools/probe_conv.py, P = 16128): hi/lo pairs are 2-4 % faster with 8 waves, plain bf16 10 % faster with 4
+  static const char *force = getenv("CRW_CONV_NW");  // diagnostics (tools/probe_conv.py): force 4 or 8 waves
+  if (force && force[0] == '4') return launch_conv_nw<SPLIT, CIN, COUT, MODE, 4>(a, s);
+  if (force && force[0] == '8') return launch_conv_nw<SPLIT, CIN, COUT, MODE, 8>(a, s);
   return launch_conv_nw<SPLIT, CIN, COUT, MODE, (SPLIT == 3 ? 8 : 4)>(a, s);
 }
 
