@@ -336,6 +336,17 @@ def crw_hip_normalize(enc, seq, T, N):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.workload in ("radargram", "dense"):
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes (nothing here has
+        # touched the GPU yet) and leave with their exit code
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: reporting n_gpus = WORLD_SIZE",
+              file=sys.stderr)
     if args.workload == "labelprop":
         import crw_hip
         crw_hip.lib()
