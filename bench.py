@@ -13,6 +13,7 @@ Rank 0 prints one JSON line.  Weak scaling: each rank processes its own radargra
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -464,26 +465,34 @@ def main():
                             "frac": pfl / (pms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], "traffic": None,
                             "launch_us": pms * 1e3, "shape": f"n={Np} batch={B}x3",
                             "note": "launch-latency bound at the reference-default node count"})
-        # HBM traffic from the committed PMC pass (profiles/r01_pmc_conv5.json; rocprofv3 cannot run inside bench)
+        # HBM traffic per launch from the committed PMC passes over this same command (rocprofv3 cannot run inside bench)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_in_step_traffic.json")))["kernels"]
             for k in kernels:
-                if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
-                    key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
-                           "conv3x3_kernel<3, 128, 128, 1, 8>" if "bwd-data" in k["kernel"] else
-                           "conv3x3_kernel<3, 128, 128, 0, 8>")
-                    wr = pmc[key].get("hbm_write_bytes", pmc[key]["algorithmic_write_bytes"])
-                    k["traffic"] = pmc[key]["hbm_read_bytes_corrected"] + wr
-                    k["traffic_note"] = ("HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_conv5.json): reads = "
-                                         "2*1024*FETCH_SIZE (gfx950 correction), writes = 1024*WRITE_SIZE where measured, else the "
-                                         f"algorithmic slab bytes; read/algorithmic = {pmc[key]['read_over_algorithmic']}, "
-                                         f"L2 hit rate {pmc[key]['l2_hit_rate']}")
+                m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
+                if not m or args.convs != "bf16x3" or B * T * N != 16128:  # the passes ran at the default workload
+                    continue
+                cin, cout = int(m.group(1)), int(m.group(2))
+                key = (f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4>" if "wgrad" in k["kernel"] else
+                       f"conv3x3_kernel<3, {cout}, {cin}, 1, 8, false>" if "bwd-data" in k["kernel"] else
+                       f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
+                if key in pmc:
+                    k["traffic"] = pmc[key]["hbm_bytes"]
+                    k["traffic_note"] = ("HBM bytes per launch INSIDE the step, committed PMC passes profiles/r01_pmc_in_step_traffic.json: "
+                                         "reads = 2*1024*FETCH_SIZE (gfx950 correction) + writes = 1024*WRITE_SIZE; read/algorithmic = "
+                                         f"{pmc[key]['read_over_algorithmic']}"
+                                         + (f", write/algorithmic = {pmc[key]['write_over_algorithmic']}"
+                                            if "write_over_algorithmic" in pmc[key] else ""))
             util = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_in_step.json")))["kernels"]
             for k in kernels:
-                if "cin=128 cout=128" in k["kernel"] and args.convs == "bf16x3":
-                    key = ("conv3x3_wgrad_kernel<3, 128, 128, 64, 4>" if "wgrad" in k["kernel"] else
-                           "conv3x3_kernel<3, 128, 128, 1, 8, false>" if "bwd-data" in k["kernel"] else
-                           "conv3x3_kernel<3, 128, 128, 0, 8, false>")
+                m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
+                if not m or args.convs != "bf16x3" or B * T * N != 16128:
+                    continue
+                cin, cout = int(m.group(1)), int(m.group(2))
+                key = (f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4>" if "wgrad" in k["kernel"] else
+                       f"conv3x3_kernel<3, {cout}, {cin}, 1, 8, false>" if "bwd-data" in k["kernel"] else
+                       f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
+                if key in util:
                     k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
                     k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
                     k["pmc_note"] = ("committed PMC pass over this same command (profiles/r01_pmc_in_step.json): "
