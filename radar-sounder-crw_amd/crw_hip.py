@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrw_hip.so")
+LIB_PATH = os.environ.get("CRW_HIP_LIB") or os.path.join(_HERE, "libcrw_hip.so")  # CRW_HIP_LIB: A/B of two builds (tools/)
 
 CRW_OK, CRW_EINVAL, CRW_EWORKSPACE, CRW_EHIP = 0, 1, 2, 3
 CHAIN_F32, CHAIN_BF16, CHAIN_BF16X3 = 0, 1, 2
