@@ -165,6 +165,30 @@ __device__ inline void zero_halo(char *plane, int tid) {
   }
 }
 
+// Which output pixel an MFMA row computes.  A ds_read_b128 is served in four groups of 16 lanes, and with the 2C+32 row
+// stride a group is conflict-free exactly when the source pixels of its two 8-lane sets -- tile rows {0-3, 12-15} and
+// {4-11} -- have padded positions (12 y + x) that are distinct mod 8.  Sixteen CONSECUTIVE output pixels break that at every
+// image-row end (the position jumps by 3): PMC showed 0.9 extra LDS cycles per cycle of fragment reads, on a kernel whose
+// LDS array is busy 96 % of the time.  So the 7 x 16 rows are dealt out by residue instead:
+//   tiles 0-4: rows 4-11 = image row 2t, x = 0..7; rows 0-3, 12-15 = image row 2t + 1, x = 0..7 (every residue once);
+//   tiles 5-6: the pixels x = 8, 9 (residues {0,1} on even image rows, {4,5} on odd ones) in four sets: three hold one even
+//   + one odd row (4 pixels; the other 4 lanes repeat them: same address = broadcast) and the last one holds image rows 6-9
+//   (a 2-way conflict: the residues 0, 1, 4, 5 occur 15 times each in 14 sets).
+// row = row inside the tile (0..15).  Returns false for a lane that only repeats another lane's pixel.
+__device__ inline bool slot_pixel(int tile, int row, int &y, int &x) {
+  const bool s2 = row >= 4 && row < 12;
+  const int q = s2 ? row - 4 : (row < 4 ? row : row - 8);
+  if (tile < 5) {
+    y = 2 * tile + (s2 ? 0 : 1);
+    x = q;
+    return true;
+  }
+  const int L = 2 * (tile - 5) + (s2 ? 1 : 0);
+  y = 2 * L + ((q >> 1) & 1) + (L == 3 ? 2 * (q >> 2) : 0);
+  x = 8 + (q & 1);
+  return q < 4 || L == 3;
+}
+
 struct ConvArgs {
   const uint16_t *xh, *xl;   // [P][100][CIN] input planes
   const uint16_t *wh, *wl;   // weights in fragment order (pack_weights_kernel; flipped/transposed for backward-data)
@@ -204,6 +228,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   constexpr int NTW = COUT / 16 / WN;                     // 16-wide column tiles per wave
   constexpr int MTW = (MT + WM - 1) / WM;                 // row tiles per wave and patch (tile wm + WM*k)
   constexpr int KCH = CIN / 32;                           // 32-deep k-steps per tap
+  // rows dealt out by bank residue (slot_pixel) where a wave owns all 7 row tiles; with row tiles split over waves
+  // (64 / 32 output channels at 8 waves) the wave-uniform tile index costs the short epilogue more than the reads gain
+  constexpr bool PERM = !MAP && WM == 1;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   int p0 = blockIdx.x, ty0 = 0, tx0 = 0;  // patch; MAP: origin of this workgroup's output tile in the map
@@ -271,9 +298,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   int abase[MTW];
 #pragma unroll
   for (int k = 0; k < MTW; ++k) {
-    int i = 16 * (wm + WM * k) + r16;
-    if (i >= NPIX) i = 0;  // dummy rows recompute pixel 0 and are dropped in the epilogue
-    abase[k] = ((i / IMG_W) * PAD_W + (i % IMG_W)) * RSI + 16 * g;
+    if constexpr (!PERM) {
+      int i = 16 * (wm + WM * k) + r16;
+      if (i >= NPIX) i = 0;  // dummy rows recompute pixel 0 and are dropped in the epilogue
+      abase[k] = ((i / IMG_W) * PAD_W + (i % IMG_W)) * RSI + 16 * g;
+    } else {
+      int y, x;
+      const int tile = wm + WM * k;
+      slot_pixel(tile < MT ? tile : 0, r16, y, x);
+      abase[k] = (y * PAD_W + x) * RSI + 16 * g;
+    }
   }
   auto tile_live = [&](int k) { return WM == 1 || wm + WM * k < MT; };  // wave-uniform
   auto step_off = [&](int step) {
@@ -386,6 +420,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
     float gsum[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) gsum[j] = 0.f;
+    // per-lane terms of slot_pixel for the accumulator rows 4 g + r (see there): tiles 0-4 / tiles 5-6
+    const int slot_pp = g == 0 ? PAD_W : g == 1 ? 0 : g == 2 ? 4 : PAD_W + 4, slot_i = g == 0 ? IMG_W : g == 1 ? 0 : g == 2 ? 4 : IMG_W + 4;
+    const int slot_pp5 = 2 * PAD_W * g, slot_i5 = 2 * IMG_W * g;
+    (void)slot_pp; (void)slot_i; (void)slot_pp5; (void)slot_i5;
 #pragma unroll
     for (int k = 0; k < MTW; ++k)
 #pragma unroll
@@ -393,9 +431,25 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
         const int co = co_w + 16 * j + r16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * (wm + WM * k) + 4 * g + r;
-          if (i < NPIX) {  // also false for the tiles a wave does not own (wm + WM k >= 7)
-            const int pp = interior_pp(i);
+          int i = 16 * (wm + WM * k) + 4 * g + r;
+          bool valid = i < NPIX;  // also false for the tiles a wave does not own (wm + WM k >= 7)
+          int pp = 0;
+          if constexpr (!PERM) {
+            if (valid) pp = interior_pp(i);
+          } else {
+            // slot_pixel(tile, 4 g + r) split into a wave-uniform part (tile, r) and the per-lane terms of the lane group g
+            const int tile = wm + WM * k;
+            if (tile < 5) {
+              i = 20 * tile + r + slot_i;
+              pp = (2 * tile + 1) * PAD_W + 1 + r + slot_pp;
+              valid = true;
+            } else {
+              i = 40 * (tile - 5) + 10 * (r >> 1) + (r & 1) + 8 + slot_i5;
+              pp = 4 * PAD_W * (tile - 5) + PAD_W * (r >> 1) + (r & 1) + 21 + slot_pp5;
+              valid = tile < MT && (g < 2 || (g == 2 && tile == 6));
+            }
+          }
+          if (valid) {
             float v = acc[k][j][r];
             if (MODE == 0) {
               v = fmaxf(v + bias_r[j], 0.f);
