@@ -1022,11 +1022,14 @@ int launch_conv_map(const ConvArgs &a, hipStream_t s) {
 
 template <int SPLIT, int CIN, int COUT, int MODE>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
-  // measured (tools/probe_conv.py, P = 16128): hi/lo pairs are 2-4 % faster with 8 waves, plain bf16 10 % faster with 4
+  // measured (tools/probe_conv.py, P = 16128): plain bf16 is 10 % faster with 4 waves than with 8
   static const char *force = getenv("CRW_CONV_NW");  // diagnostics (tools/probe_conv.py): force 4 or 8 waves
   if (force && force[0] == '4') return launch_conv_nw<SPLIT, CIN, COUT, MODE, 4>(a, s);
   if (force && force[0] == '8') return launch_conv_nw<SPLIT, CIN, COUT, MODE, 8>(a, s);
-  return launch_conv_nw<SPLIT, CIN, COUT, MODE, (SPLIT == 3 ? 8 : 4)>(a, s);
+  // in-step A/B (tools/ab_kernels.py, CRW_CONV_NW): hi/lo pairs run best with 8 waves except at 32 output channels
+  // (conv3 backward-data, where 8 waves leave a wave 2 of the 7 row tiles: 4 waves are 6-9 % faster); 64 output channels
+  // measured the same either way or box-dependent
+  return launch_conv_nw<SPLIT, CIN, COUT, MODE, (SPLIT == 3 && COUT != 32 ? 8 : 4)>(a, s);
 }
 
 // input channels per workgroup (one 16-channel tile per wave)
