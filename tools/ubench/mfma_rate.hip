@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, long long *cyc) 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
-      else acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, acc[i], 0, 0, 0);
+      else if (KIND == 1) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, acc[i], 0, 0, 0);
+      else acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[0], 0, 0, 0);  // ONE accumulation chain: measured 18.0 cycles per MFMA for a lone wave (2.09 PFLOP/s chip)
+      // (rotating over several accumulators makes hipcc shuffle AGPRs inside this loop: read the ISA before trusting KIND 0 / 1)
     }
   }
   long long t1 = __builtin_amdgcn_s_memtime();
@@ -49,5 +51,6 @@ int main() {
   run<0>("v_mfma_f32_16x16x32_bf16", 16384.0);
   run<1>("v_mfma_f32_16x16x16_bf16 (1k)", 8192.0);
   run<0>("v_mfma_f32_16x16x32_bf16", 16384.0);
+  run<2>("v_mfma_f32_16x16x32_bf16, ONE accumulation chain", 16384.0);
   return 0;
 }
