@@ -474,7 +474,7 @@ def main():
                     continue
                 cin, cout = int(m.group(1)), int(m.group(2))
                 key = (f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4>" if "wgrad" in k["kernel"] else
-                       f"conv3x3_kernel<3, {cout}, {cin}, 1, 8, false>" if "bwd-data" in k["kernel"] else
+                       f"conv3x3_kernel<3, {cout}, {cin}, 1, {4 if cin == 32 else 8}, false>" if "bwd-data" in k["kernel"] else
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
                 if key in pmc:
                     k["traffic"] = pmc[key]["hbm_bytes"]
@@ -490,7 +490,7 @@ def main():
                     continue
                 cin, cout = int(m.group(1)), int(m.group(2))
                 key = (f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4>" if "wgrad" in k["kernel"] else
-                       f"conv3x3_kernel<3, {cout}, {cin}, 1, 8, false>" if "bwd-data" in k["kernel"] else
+                       f"conv3x3_kernel<3, {cout}, {cin}, 1, {4 if cin == 32 else 8}, false>" if "bwd-data" in k["kernel"] else
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
                 if key in util:
                     k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
