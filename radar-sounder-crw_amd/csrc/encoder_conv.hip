@@ -890,25 +890,26 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float *__restrict_
   }
 }
 
-// few outputs, many slices (bias gradients): one wave per output, lanes stride the slices, fixed shuffle tree
-__global__ __launch_bounds__(256) void slice_sum_wave_kernel(const float *__restrict__ part, int nslice, long stride,
-                                                             int n, float *__restrict__ out) {
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (e >= n) return;
-  float s = 0.f;
-  for (int k = lane; k < nslice; k += 64) s += part[(long)k * stride + e];
-  s = wave_sum(s);
-  if (lane == 0) out[e] = s;
-}
-
-// same for the weight gradient: slabs are [tap][co*ci], the result is the framework layout [co*ci][tap].
+// The weight gradient: slabs are [tap][co*ci], the result is the framework layout [co*ci][tap].
 // A block owns 64 consecutive slab elements; its 4 waves each add a quarter of the slices (8 independent
 // loads in flight per lane), the quarters meet in LDS in a fixed order (deterministic).
+// The blocks past nblk_dw add the bias-gradient slices (few outputs, many slices): one wave per output, lanes stride the
+// slices, fixed shuffle tree -- one launch for both.
 __global__ __launch_bounds__(256) void slice_sum_dw_kernel(const float *__restrict__ part, int nslice, int coci,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, int nblk_dw,
+                                                           const float *__restrict__ bpart, int cout, float *__restrict__ bout) {
   __shared__ float red[4][64];
   const long n = 9L * coci;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= nblk_dw) {  // block-uniform
+    const int e = ((int)blockIdx.x - nblk_dw) * 4 + q;
+    if (e >= cout) return;
+    float s = 0.f;
+    for (int k = lane; k < nslice; k += 64) s += bpart[(long)k * cout + e];
+    s = wave_sum(s);
+    if (lane == 0) bout[e] = s;
+    return;
+  }
   const long e = (long)blockIdx.x * 64 + lane;
   const int per = (nslice + 3) / 4, k0 = q * per, k1 = min(nslice, k0 + per);
   float s = 0.f;
@@ -1189,8 +1190,9 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
 #undef CRW_WG_CASE
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
-  hipLaunchKernelGGL(slice_sum_dw_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, dw_part, nslice, cout * cin, dw);
-  hipLaunchKernelGGL(slice_sum_wave_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, db_part, nslice, (long)cout, cout, db);
+  const int nblk_dw = (int)((nw + 63) / 64);
+  hipLaunchKernelGGL(slice_sum_dw_kernel, dim3((unsigned)(nblk_dw + (cout + 3) / 4)), dim3(256), 0, s, dw_part, nslice, cout * cin,
+                     dw, nblk_dw, db_part, cout, db);
   return check_launch();
 }
 

@@ -699,14 +699,23 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
 
 // out[e] = sum_k part[k * stride + e], e < n: one wave per output, lanes stride the slices, fixed
 // shuffle tree (deterministic)
-__global__ __launch_bounds__(256) void front_slice_sum_kernel(const float *__restrict__ part, int nslice, int stride,
-                                                              int n, float *__restrict__ out) {
+// (the four gradient tensors are consecutive segments of a slice's partial vector: one launch covers them all)
+struct FrontSums {
+  const float *part;
+  int nslice, stride, n;
+  int end[4];     // exclusive end of segment i in the partial vector
+  float *dst[4];  // its output tensor
+};
+__global__ __launch_bounds__(256) void front_slice_sum_kernel(FrontSums a) {
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (e >= n) return;
+  if (e >= a.n) return;
   float s = 0.f;
-  for (int k = lane; k < nslice; k += 64) s += part[(long)k * stride + e];
+  for (int k = lane; k < a.nslice; k += 64) s += a.part[(long)k * a.stride + e];
   s = wave_sum(s);
-  if (lane == 0) out[e] = s;
+  if (lane == 0) {
+    const int seg = e < a.end[0] ? 0 : e < a.end[1] ? 1 : e < a.end[2] ? 2 : 3;
+    a.dst[seg][e - (seg ? a.end[seg - 1] : 0)] = s;
+  }
 }
 
 size_t fwd_lds_bytes(int cin, bool pad = false) {
@@ -826,10 +835,8 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
   const int n2 = 32 * 8 * 25, n1 = 8 * cin * 25, PART = n2 + 32 + n1 + 8;
   // the partial layout is [dW2 | db2 | dW1 | db1]; the outputs are four separate tensors
   float *part = (float *)ws;
-  struct Seg { int off, n; float *dst; } segs[4] = {{0, n2, dw2}, {n2, 32, db2}, {n2 + 32, n1, dw1}, {n2 + 32 + n1, 8, db1}};
-  for (auto &sg : segs)
-    hipLaunchKernelGGL(front_slice_sum_kernel, dim3((sg.n + 3) / 4), dim3(256), 0, s, part + sg.off, nslice, PART,
-                       sg.n, sg.dst);
+  FrontSums fs{part, nslice, PART, n2 + 32 + n1 + 8, {n2, n2 + 32, n2 + 32 + n1, n2 + 32 + n1 + 8}, {dw2, db2, dw1, db1}};
+  hipLaunchKernelGGL(front_slice_sum_kernel, dim3((fs.n + 3) / 4), dim3(256), 0, s, fs);
   return check_launch();
 }
 
