@@ -21,6 +21,15 @@ namespace {
 
 constexpr float EPS_NORM = 1e-12f;  // F.normalize default eps
 
+// three equally long slices zeroed by one launch (the gradient slices no chain product writes)
+__global__ __launch_bounds__(256) void zero3_kernel(float *__restrict__ a, float *__restrict__ b, float *__restrict__ c, long n4) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    reinterpret_cast<float4 *>(a)[e] = float4{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<float4 *>(b)[e] = float4{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<float4 *>(c)[e] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ e, long rows, int C,
                                                         float *__restrict__ ehat, float *__restrict__ norm) {
   const int lane = threadIdx.x & 63;
@@ -316,9 +325,17 @@ int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state
   CRW_TRY(launch_dAt(st.At.f, st.lse, gloss, coef, K * B, N, Np, sc.dAt.f, nullptr, s));
   CRW_TRY(make_images(sc.dAt, K * BM, s));
   // slices no product writes: dF_0, dF_{T-2}, dGt_{T-2}
-  if (hipMemsetAsync(sc.dF.f, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
-  if (hipMemsetAsync(sc.dF.f + (long)(T - 2) * BM, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
-  if (hipMemsetAsync(sc.dGt.f + (long)(T - 2) * BM, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
+  if ((reinterpret_cast<uintptr_t>(sc.dF.f) | reinterpret_cast<uintptr_t>(sc.dGt.f)) & 15) {  // caller's scratch not 16-byte aligned
+    if (hipMemsetAsync(sc.dF.f, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
+    if (hipMemsetAsync(sc.dF.f + (long)(T - 2) * BM, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
+    if (hipMemsetAsync(sc.dGt.f + (long)(T - 2) * BM, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
+  } else {  // BM = B * Np^2 with Np a multiple of 32: float4 stores
+    const long n4 = BM / 4;
+    const long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(zero3_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, sc.dF.f,
+                       sc.dF.f + (long)(T - 2) * BM, sc.dGt.f + (long)(T - 2) * BM, n4);
+    CRW_TRY(check_launch());
+  }
 
   {  // k-local terms for every k at once: dLt_k = R_k dAt_k^T, dR_k = Lt_k dAt_k
     GemmGroup g{};
