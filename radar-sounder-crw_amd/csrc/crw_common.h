@@ -117,7 +117,9 @@ int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const f
 int launch_chain_small_fwd(const float *Gt, const float *F, float *Lt, float *R, int B, int K, int n, hipStream_t s);
 int launch_chain_small_bwd(const float *Gt, const float *F, float *dLt, float *dR, int B, int K, int n,
                            hipStream_t s);
-int launch_identity(float *R, void *Rb, int batch, int Np, int N, hipStream_t s);
+// R (fp32) and / or Rb (bf16) = identity on the first N rows; optionally also copy_dst = copy_src (batch * Np * Np floats)
+int launch_identity(float *R, void *Rb, int batch, int Np, int N, hipStream_t s, float *copy_dst = nullptr,
+                    const float *copy_src = nullptr);
 int launch_copy_f32(float *dst, const float *src, long dst_bs, long src_bs, long n_per_batch, int batch,
                     hipStream_t s);
 int launch_loss_rows(const float *At, int nmat, int N, int Np, float *lse, float *terms, hipStream_t s);

@@ -14,10 +14,10 @@ __device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (
 
 // ---- forward statistics -------------------------------------------------------------------
 // one wave per row: rmax[n], rsum[n]
-__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ A, int B, int Tm1, int N, int Np,
-                                                        float *__restrict__ rmax, float *__restrict__ rsum) {
+__device__ inline void row_stats_block(int bx, const float *__restrict__ A, int B, int Tm1, int N, int Np,
+                                       float *__restrict__ rmax, float *__restrict__ rsum) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
+  const int row = bx * 4 + wave;
   const long mat = blockIdx.y, amat = (mat % B) * Tm1 + mat / B;  // internal [j][b]  <->  caller's [b][j]
   if (row >= N) return;
   const float *a = A + amat * N * N + (long)row * N;
@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 }
 
 // one lane per column (64 columns per block), the 4 waves split the rows: cmax[m], csum[m]
-__global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ A, int B, int Tm1, int N, int Np,
-                                                        float *__restrict__ cmax, float *__restrict__ csum) {
+__device__ inline void col_stats_block(int bx, const float *__restrict__ A, int B, int Tm1, int N, int Np,
+                                       float *__restrict__ cmax, float *__restrict__ csum) {
   __shared__ float sm[4][64], ss[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+  const int col = bx * 64 + lane;
   const long mat = blockIdx.y, amat = (mat % B) * Tm1 + mat / B;
   const float *a = A + amat * N * N;
   float m = -INFINITY;
@@ -56,6 +56,14 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     cmax[mat * Np + col] = m;
     csum[mat * Np + col] = (ss[0][lane] + ss[1][lane]) + (ss[2][lane] + ss[3][lane]);
   }
+}
+
+// both statistics in one launch: blocks [0, nrow) take rows, the rest columns (block-uniform branch)
+__global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ A, int B, int Tm1, int N, int Np, int nrow,
+                                                    float *__restrict__ rmax, float *__restrict__ rsum,
+                                                    float *__restrict__ cmax, float *__restrict__ csum) {
+  if ((int)blockIdx.x < nrow) row_stats_block(blockIdx.x, A, B, Tm1, N, Np, rmax, rsum);
+  else col_stats_block((int)blockIdx.x - nrow, A, B, Tm1, N, Np, cmax, csum);
 }
 
 // elementwise: F, Gt padded (+ optional bf16 shadows)
@@ -86,10 +94,10 @@ __global__ __launch_bounds__(256) void softmax_write_kernel(const float *__restr
 }
 
 // ---- backward statistics (padded operands: pads are zero, no bounds needed) -----------------
-__global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ X, const float *__restrict__ dX,
-                                                      int Np, float *__restrict__ rdot) {
+__device__ inline void row_dot_block(int bx, const float *__restrict__ X, const float *__restrict__ dX, int Np,
+                                     float *__restrict__ rdot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
+  const int row = bx * 4 + wave;
   const long mat = blockIdx.y;
   if (row >= Np) return;
   const long off = mat * Np * Np + (long)row * Np;
@@ -99,11 +107,11 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ 
   if (lane == 0) rdot[mat * Np + row] = s;
 }
 
-__global__ __launch_bounds__(256) void col_dot_kernel(const float *__restrict__ X, const float *__restrict__ dX,
-                                                      int Np, float *__restrict__ cdot) {
+__device__ inline void col_dot_block(int bx, const float *__restrict__ X, const float *__restrict__ dX, int Np,
+                                     float *__restrict__ cdot) {
   __shared__ float ss[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;  // Np is a multiple of 32; guard the last half strip
+  const int col = bx * 64 + lane;  // Np is a multiple of 32; guard the last half strip
   const long mat = blockIdx.y;
   float s = 0.f;
   if (col < Np)
@@ -114,6 +122,14 @@ __global__ __launch_bounds__(256) void col_dot_kernel(const float *__restrict__ 
   ss[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && col < Np) cdot[mat * Np + col] = (ss[0][lane] + ss[1][lane]) + (ss[2][lane] + ss[3][lane]);
+}
+
+// row dots of (F, dF) and column dots of (Gt, dGt) in one launch
+__global__ __launch_bounds__(256) void dots_kernel(const float *__restrict__ F, const float *__restrict__ dF,
+                                                   const float *__restrict__ Gt, const float *__restrict__ dGt, int Np,
+                                                   int nrow, float *__restrict__ rdot, float *__restrict__ cdot) {
+  if ((int)blockIdx.x < nrow) row_dot_block(blockIdx.x, F, dF, Np, rdot);
+  else col_dot_block((int)blockIdx.x - nrow, Gt, dGt, Np, cdot);
 }
 
 // dA = F (dF - rdot[n]) + Gt (dGt - cdot[m])   -> dense [nmat][N][N]
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_write_kernel(const float *__r
 
 // ---- fills / copies -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void identity_kernel(float *__restrict__ R, uint16_t *__restrict__ Rb, int Np,
-                                                       int N) {
+                                                       int N, float *__restrict__ cdst, const float *__restrict__ csrc) {
   const long mat = blockIdx.y;
   const long per = (long)Np * Np;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < per; idx += (long)gridDim.x * 256) {
@@ -143,6 +159,7 @@ __global__ __launch_bounds__(256) void identity_kernel(float *__restrict__ R, ui
     const float v = (i == j && i < N) ? 1.f : 0.f;
     if (R) R[mat * per + idx] = v;
     if (Rb) Rb[mat * per + idx] = f2bf(v);
+    if (cdst) cdst[mat * per + idx] = csrc[mat * per + idx];  // (the walk's Lt_1 = Gt_0 rides along: one launch fewer)
   }
 }
 
@@ -235,8 +252,8 @@ int launch_softmax_fwd(const float *A, int B, int Tm1, int N, int Np, float *F, 
                        float *stats, hipStream_t s) {
   const int nmat = B * Tm1;
   float *rmax = stats, *rsum = stats + (long)nmat * Np, *cmax = stats + 2L * nmat * Np, *csum = stats + 3L * nmat * Np;
-  hipLaunchKernelGGL(row_stats_kernel, dim3((N + 3) / 4, nmat), dim3(256), 0, s, A, B, Tm1, N, Np, rmax, rsum);
-  hipLaunchKernelGGL(col_stats_kernel, dim3((N + 63) / 64, nmat), dim3(256), 0, s, A, B, Tm1, N, Np, cmax, csum);
+  hipLaunchKernelGGL(stats_kernel, dim3((N + 3) / 4 + (N + 63) / 64, nmat), dim3(256), 0, s, A, B, Tm1, N, Np, (N + 3) / 4,
+                     rmax, rsum, cmax, csum);
   hipLaunchKernelGGL(softmax_write_kernel, dim3(ew_blocks((long)Np * Np), nmat), dim3(256), 0, s, A, B, Tm1, N, Np, rmax,
                      rsum, cmax, csum, F, Gt, (uint16_t *)Fb, (uint16_t *)Gtb);
   return check_launch();
@@ -246,16 +263,16 @@ int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const f
                        int Np, float *stats, float *dA, hipStream_t s) {
   const int nmat = B * Tm1;
   float *rdot = stats, *cdot = stats + (long)nmat * Np;
-  hipLaunchKernelGGL(row_dot_kernel, dim3((Np + 3) / 4, nmat), dim3(256), 0, s, F, dF, Np, rdot);
-  hipLaunchKernelGGL(col_dot_kernel, dim3((Np + 63) / 64, nmat), dim3(256), 0, s, Gt, dGt, Np, cdot);
+  hipLaunchKernelGGL(dots_kernel, dim3((Np + 3) / 4 + (Np + 63) / 64, nmat), dim3(256), 0, s, F, dF, Gt, dGt, Np,
+                     (Np + 3) / 4, rdot, cdot);
   hipLaunchKernelGGL(softmax_bwd_write_kernel, dim3(ew_blocks((long)N * N), nmat), dim3(256), 0, s, F, Gt, dF, dGt,
                      rdot, cdot, B, Tm1, N, Np, dA);
   return check_launch();
 }
 
-int launch_identity(float *R, void *Rb, int batch, int Np, int N, hipStream_t s) {
+int launch_identity(float *R, void *Rb, int batch, int Np, int N, hipStream_t s, float *copy_dst, const float *copy_src) {
   hipLaunchKernelGGL(identity_kernel, dim3(ew_blocks((long)Np * Np), batch), dim3(256), 0, s, R, (uint16_t *)Rb,
-                     Np, N);
+                     Np, N, copy_dst, copy_src);
   return check_launch();
 }
 

@@ -261,8 +261,7 @@ int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, si
   CRW_TRY(make_images(st.F, (long)nA * M, s));
   CRW_TRY(make_images(st.Gt, (long)nA * M, s));
   if (chain == CRW_CHAIN_F32) {
-    CRW_TRY(launch_copy_f32(st.Lt.f, st.Gt.f, 0, 0, BM, 1, s));  // Lt_1 = Gt_0
-    CRW_TRY(launch_identity(st.R.f, nullptr, B, Np, N, s));      // R_1 = I
+    CRW_TRY(launch_identity(st.R.f, nullptr, B, Np, N, s, st.Lt.f, st.Gt.f));  // R_1 = I and Lt_1 = Gt_0
   } else {  // the same on the bf16 images (two bf16 per float lane of the copy kernel)
     CRW_TRY(launch_copy_f32((float *)st.Lt.h, (const float *)st.Gt.h, 0, 0, BM / 2, 1, s));
     if (st.Lt.l) CRW_TRY(launch_copy_f32((float *)st.Lt.l, (const float *)st.Gt.l, 0, 0, BM / 2, 1, s));
