@@ -578,10 +578,14 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
       //   ah x [Wh | Wl] -> columns 0-7 = ah*Wh, 8-15 = ah*Wl        al x [Wh | ..] -> columns 0-7 = al*Wh
       // two MFMAs and three LDS reads per tap instead of three and four; the halves meet in a lane shift.
       f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f}, dacc1 = dacc;
-      if (wave < 11) {  // 169 pixels -> 11 row tiles, one per wave (wave-uniform)
-        int i = 16 * wave + r16;
-        if (i >= A1W * A1W) i = 0;
-        const int base = ((i / A1W) + 5) * D2PW + (i % A1W) + 5;  // padded dC2 pixel of tap (0,0); tap shifts by -(ty*19 + tx)
+      // One image row of dA1 (13 pixels) per wave, dealt to the MFMA rows by LDS bank residue: a ds_read_b128 is served in
+      // 16-lane groups made of tile rows {0-3, 12-15} and {4-11}, conflict-free on these 32-byte pixel rows iff the pixel
+      // positions inside each set are distinct mod 8 -- rows 4-11 take x = 0..7, rows 0-3 and 12 take x = 8..12, rows 13-15
+      // repeat x = 12 (same address: broadcast).  Sixteen consecutive pixels of the 13-wide map (11 tiles) broke that at
+      // every row end; 13 tiles cost nothing, 5 of the 16 waves were idle in this phase.
+      if (wave < A1W) {  // wave-uniform
+        const int xl = (r16 >= 4 && r16 < 12) ? r16 - 4 : (r16 < 4 ? 8 + r16 : 12);
+        const int base = (wave + 5) * D2PW + xl + 5;  // padded dC2 pixel of tap (0,0); tap shifts by -(ty*19 + tx)
         // B: backward weights, LDS layout [tap][co half][8 ci][16 co]: lane (ci = r16 & 7, k chunk g = co 8g..8g+7)
         const char *wb = ((SPLIT == 3 && r16 >= 8) ? wbl : wbh) + (g >> 1) * 256 + (r16 & 7) * 32 + (g & 1) * 16;
         // taps shift the A pixel by -(ty*19 + tx); rebased so that every tap is a non-negative immediate
@@ -604,11 +608,12 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
         }
       }
       lds_barrier();  // dyb (aliased by dA1) is no longer read
-      if (wave < 11 && r16 < 8)
+      if (wave < A1W && r16 < 8)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * wave + 4 * g + r;
-          if (i < A1W * A1W) dA1[i * 8 + r16] = dacc[r];
+          const int row = 4 * g + r;  // tile row -> x as above; rows 13-15 only repeated pixel 12
+          const int x = (row >= 4 && row < 12) ? row - 4 : (row < 4 ? 8 + row : 12);
+          if (row < 13) dA1[(wave * A1W + x) * 8 + r16] = dacc[r];
         }
     }
     lds_barrier();
