@@ -54,6 +54,7 @@ def parse():
                          "(N = 497 nodes per column)")
     ap.add_argument("--nodes", type=int, default=4096, help="N of the chain workload")
     ap.add_argument("--walk", type=int, default=32, help="T (frames) of the chain workload")
+    ap.add_argument("--modes", default="f32,bf16x3,bf16", help="chain arithmetics the chain workload runs (profiling one at a time)")
     return ap.parse_args()
 
 
@@ -183,6 +184,8 @@ def bench_chain(args):
     res, ref_loss = {}, None
     for name, chain, mult in (("f32", crw_hip.CHAIN_F32, 1), ("bf16x3", crw_hip.CHAIN_BF16X3, 3),
                               ("bf16", crw_hip.CHAIN_BF16, 1)):
+        if name not in args.modes.split(","):
+            continue
         Np = crw_hip.padded_nodes(N, chain)
 
         def step():
@@ -316,6 +319,11 @@ def bench_labelprop(args):
     ref = orc.labelprop(emb, seed.cpu().numpy(), M, cfg["CXT_SIZE"], cfg["RADIUS"], cfg["TEMP"], cfg["KNN"])
     dcpu = time.time() - tc
     match = float((p2.cpu().numpy() == ref).mean())
+    # free-running maps may differ downstream of fp32 near-ties; the teacher-forced fp64 audit says whether any differing
+    # label is NOT a near-tie (oracle.labelprop_tie_audit; must be 0)
+    _, Ldev = lp.propagate_all(feats, seed, M)
+    audit = orc.labelprop_tie_audit(emb, Ldev.cpu().numpy(), p2.cpu().numpy(), cfg["CXT_SIZE"], cfg["RADIUS"], cfg["TEMP"],
+                                    cfg["KNN"], eps=1e-5)
     print(json.dumps({"metric": "label-map columns/sec (user-seed label propagation)", "value": W / dt, "unit": "radargram columns/s",
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                       "data": "synthetic", "dtype": "f32",
@@ -325,7 +333,8 @@ def bench_labelprop(args):
                                          "what": "crw_labelprop_topk + crw_labelprop_gather, features resident"},
                       "cpu_baseline": {"value": W / dcpu, "unit": "radargram columns/s", "kind": "port", "cores": torch.get_num_threads(),
                                        "sample": f"oracle labelprop (numpy) on the same features, one pass, {dcpu:.2f} s"},
-                      "label_agreement_with_oracle": match}), flush=True)
+                      "label_agreement_with_oracle": match, "label_mismatches_not_ties": audit["not_ties"],
+                      "tie_audit": audit}), flush=True)
 
 
 def crw_hip_normalize(enc, seq, T, N):

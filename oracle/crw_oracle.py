@@ -22,6 +22,7 @@ Reference lines each function follows (paths under the reference repo):
   band_bias ............... src/imported/maskedatt.py:222-245 + labelprop.py:89-96 (w == 1)
   labelprop_weights ....... src/imported/maskedatt.py:151-175
   labelprop ............... src/utils.py:134-161 + src/imported/labelprop.py:67-115
+  labelprop_tie_audit ..... same lines, fp64, teacher-forced per frame (near-tie proof for label maps)
   seed_labels ............. src/utils.py:139-147       (NEAREST resize to (N,1))
   xent_metric ............. src/utils.py:117-125
   unfold_item ............. src/dataset.py:19-39
@@ -272,6 +273,64 @@ def labelprop(emb, seed, nclasses, cxt_size, radius, temp, knn, dtype=np.float32
         L[n * N:(n + 1) * N] = p
         pred[:, n] = p.argmax(-1)
     return pred
+
+
+def labelprop_tie_audit(ehat, L_dev, pred_dev, cxt_size, radius, temp, knn, eps=1e-5):
+    """Frame-by-frame (teacher-forced) fp64 audit of a propagated label map -- how the tests prove that every label
+    on which a device run and the fp32 oracle disagree is a floating-point near-tie, not a defect.
+
+    Label propagation is argmax / top-k over floating-point scores, so two correct fp32 implementations (different
+    summation orders) can legitimately pick different labels where two class probabilities or the k-th and (k+1)-th key
+    logits coincide to rounding, and one such flip then cascades through every later frame that uses the flipped
+    labels as context.  This audit removes the cascade: for every frame n it recomputes, in fp64 and with the DEVICE's
+    own soft labels of frames < n as context (``L_dev`` [T*N, M]; same index quirk Q7 as ``labelprop``), the scores of
+    frame n from the device's normalised features ``ehat`` [T,N,C], and compares argmax with ``pred_dev`` [N,T].
+
+    Returns dict(step_mismatches, not_ties, worst_margin, max_soft_err): a step mismatch is a *tie* when the fp64
+    top-2 class-probability margin is < eps or the top-k boundary logit gap (k-th minus (k+1)-th key logit of that
+    query) is < eps; ``not_ties`` must be 0.  ``max_soft_err`` = max |L_dev - fp64 soft labels| over the queries
+    without a boundary tie (the gathered weights themselves)."""
+    T, N, C = ehat.shape
+    eh = np.asarray(ehat, np.float64)
+    L = np.asarray(L_dev, np.float64)
+    M = L.shape[1]
+    bias = band_bias(N, radius, np.float64)
+    out = dict(step_mismatches=0, not_ties=0, worst_margin=0.0, max_soft_err=0.0, boundary_ties=0)
+    for n in range(1, T):
+        S = (eh[:n].reshape(n * N, C) @ eh[n].T).reshape(n, N, N) + bias[None]
+        S = S.reshape(n * N, N) / temp
+        if S.shape[0] > (cxt_size + 1) * N:
+            S = np.concatenate([S[:N], S[-N * cxt_size:]], 0)
+        order = np.argsort(-S, axis=0, kind="stable")
+        I = order[:knn]
+        top = np.take_along_axis(S, I, 0)
+        if S.shape[0] > knn:
+            nxt = np.take_along_axis(S, order[knn:knn + 1], 0)[0]
+            gap = top[-1] - nxt                      # masked keys sit at -1e10/temp: a huge gap, never a tie
+        else:
+            gap = np.full(N, np.inf)
+        # ties INSIDE the selected set do not matter (same keys, same weights); only the boundary does
+        Wl = np.exp(top - top.max(0, keepdims=True))
+        W = Wl / Wl.sum(0, keepdims=True)
+        p = (L[I] * W[..., None]).sum(0)             # [N, M]
+        ps = np.sort(p, -1)
+        margin = ps[:, -1] - ps[:, -2] if M > 1 else np.full(N, np.inf)
+        lab = p.argmax(-1)
+        dev = np.asarray(pred_dev[:, n]).astype(np.int64)
+        boundary_tie = gap < eps
+        out["boundary_ties"] += int(boundary_tie.sum())
+        clean = ~boundary_tie
+        if clean.any():
+            out["max_soft_err"] = max(out["max_soft_err"], float(np.abs(L[n * N:(n + 1) * N][clean] - p[clean]).max()))
+        bad = lab != dev
+        # a device label different from the fp64 argmax is fine when the device's class is within eps of the best one
+        dev_short = ps[:, -1] - p[np.arange(N), dev]
+        out["step_mismatches"] += int(bad.sum())
+        nt = bad & ~boundary_tie & ~(dev_short < eps)
+        out["not_ties"] += int(nt.sum())
+        if bad.any():
+            out["worst_margin"] = max(out["worst_margin"], float(np.where(boundary_tie, 0.0, dev_short)[bad].max()))
+    return out
 
 
 def xent_metric(emb, dtype=np.float32):

@@ -10,6 +10,9 @@ import os
 import torch
 import torch.distributed as dist
 
+# which collective the last `FlatGradBucket.all_reduce_mean` issued ("nccl:avg", "gloo:sum/div" or None) -- diagnostics / tests
+LAST_COLLECTIVE = None
+
 
 def init_from_env(backend=None):
     """-> (rank, world_size, local_rank).  Initialises torch.distributed when launched by
@@ -74,10 +77,14 @@ class FlatGradBucket:
             if any(g.data_ptr() != v.data_ptr() for g, v in zip(grads, self._views)):  # not already bound
                 torch.cat(grads, out=self.flat)
             self._bind()
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        global LAST_COLLECTIVE
+        LAST_COLLECTIVE = None
+        if dist.is_initialized():  # also with one rank: the collective then is the identity, and is exercised
             if dist.get_backend() == "nccl":
                 dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+                LAST_COLLECTIVE = "nccl:avg"
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
                 self.flat.div_(dist.get_world_size())
+                LAST_COLLECTIVE = "gloo:sum/div"
         return self.flat

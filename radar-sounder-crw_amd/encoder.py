@@ -36,25 +36,33 @@ class _HipEncoder(torch.autograd.Function):
         y5h, _, _, gap = crw_hip.enc_conv3x3(0, split, y4h, y4l, packed[2][0], packed[2][1], 128, bias=b5, gap=True,
                                              lo_plane=False)  # only the sign of y5 is needed later
         ctx.split = split
-        ctx.saved = (x, w1.detach(), b1.detach(), b2.detach(), w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h)
-        ctx.bwd_w = [(pk[2], pk[3]) for pk in packed]
+        # lo planes are None for plain bf16; everything goes through save_for_backward (in-place weight updates between
+        # forward and backward are detected, a second backward without retain_graph raises autograd's own error)
+        ctx.save_for_backward(x, w1.detach(), b1.detach(), b2.detach(), *w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h,
+                              *[t for pk in packed for t in (pk[2], pk[3])])
         return gap
 
     @staticmethod
     def backward(ctx, dgap):
         import crw_hip
         s = ctx.split
-        x, w1, b1, b2, w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h = ctx.saved
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("the fused HIP encoder does not produce a gradient for its input patches (the reference never "
+                               "asks for one); set CNN.hip_convs = None to differentiate with respect to the input")
+        sv = ctx.saved_tensors
+        x, w1, b1, b2 = sv[:4]
+        w2p = sv[4:8]
+        x3h, x3l, y3h, y3l, y4h, y4l, y5h = sv[8:15]
+        bwd_w = [(sv[15], sv[16]), (sv[17], sv[18]), (sv[19], sv[20])]
         # dY5 = dgap/100 gated by y5 > 0 (ReLU5 + GAP backward) is built inside the two kernels' loaders
         dgap = dgap.contiguous().float()
         dw5, db5 = crw_hip.enc_wgrad(s, y5h, None, y4h, y4l, dgap=dgap)
-        d4h, d4l, _, _ = crw_hip.enc_conv3x3(1, s, y5h, None, *ctx.bwd_w[2], 128, mask=y4h, dgap=dgap)  # dY4
+        d4h, d4l, _, _ = crw_hip.enc_conv3x3(1, s, y5h, None, *bwd_w[2], 128, mask=y4h, dgap=dgap)  # dY4
         dw4, db4 = crw_hip.enc_wgrad(s, d4h, d4l, y3h, y3l)
-        d3h, d3l, _, _ = crw_hip.enc_conv3x3(1, s, d4h, d4l, *ctx.bwd_w[1], 64, mask=y3h)    # dY3
+        d3h, d3l, _, _ = crw_hip.enc_conv3x3(1, s, d4h, d4l, *bwd_w[1], 64, mask=y3h)    # dY3
         dw3, db3 = crw_hip.enc_wgrad(s, d3h, d3l, x3h, x3l)
-        _, _, dx3, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *ctx.bwd_w[0], 32, planes=False, f32=True)  # [P,100,32]
+        _, _, dx3, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *bwd_w[0], 32, planes=False, f32=True)  # [P,100,32]
         dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3)
-        ctx.saved = None
         return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
 class _HipLinear(torch.autograd.Function):

@@ -36,15 +36,15 @@ class _WalkLoss(torch.autograd.Function):
     def forward(ctx, A, chain):
         B, Tm1, N, _ = A.shape
         loss, state, _ = crw_hip.walk_fwd(A.contiguous(), chain)
-        ctx.state, ctx.dims, ctx.chain = state, (B, Tm1 + 1, N), chain
+        ctx.save_for_backward(state)  # freed by autograd after backward (kept under retain_graph)
+        ctx.dims, ctx.chain = (B, Tm1 + 1, N), chain
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
         B, T, N = ctx.dims
-        dA = crw_hip.walk_bwd(gloss, ctx.state, B, T, N, ctx.chain)
-        ctx.state = None
-        return dA, None
+        (state,) = ctx.saved_tensors
+        return crw_hip.walk_bwd(gloss, state, B, T, N, ctx.chain), None
 
 
 def affinity(emb, tau):

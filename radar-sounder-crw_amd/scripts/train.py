@@ -59,7 +59,9 @@ def get_args_parser():
     return p
 
 
-def main(args):
+def main(args, on_step=None):
+    """on_step(step_index, loss): optional observer called after every optimizer step with the step's (detached, on-device)
+    loss of this rank."""
     rank, world, local = crw_dist.init_from_env()
     if rank == 0:
         print(args)
@@ -76,6 +78,12 @@ def main(args):
     if args.batch_size % world:
         raise SystemExit(f'--batch_size {args.batch_size} must be a multiple of the number of ranks ({world})')
     per_rank = args.batch_size // world
+    # Like a DataLoader with drop_last=True the tail of an epoch that does not fill a global batch is dropped (the
+    # reference's loader keeps a final partial batch, scripts/train.py:53): equal shards per rank are what make the mean of
+    # the rank gradients the global gradient.  A dataset shorter than one batch would silently train nothing: refuse it.
+    if len(dataset) < args.batch_size:
+        raise SystemExit(f'the dataset holds {len(dataset)} items, fewer than one global batch (--batch_size {args.batch_size}): '
+                         'no step would run; lower --batch_size or --seq_length, or use a longer radargram')
     if args.shared_encode and not hasattr(dataset, 'columns'):
         raise SystemExit('--shared_encode needs the overlapping dataset (--dataset_full True)')
 
@@ -115,6 +123,8 @@ def main(args):
             optimizer.step()
             loss_epoch.append(loss.detach())
             nsteps += 1
+            if on_step is not None:
+                on_step(nsteps, loss_epoch[-1])
             if args.steps and nsteps >= args.steps:
                 break
         mean = torch.stack(loss_epoch).mean() if loss_epoch else torch.zeros((), device=device)

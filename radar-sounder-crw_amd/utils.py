@@ -102,9 +102,11 @@ def propagate(seq, seg_ref, model, lp, nclasses, do_pos_embed, use_last):
         x = pos_embed(x)
     emb = model(x).reshape(T, N, -1).float().contiguous()
     feats = crw_hip.normalize(emb)
+    seed = seed_labels(seg_ref.to(feats.device), N)
+    if T == 1:  # a one-frame item (the correction step of test_all.py can ask for it): nothing to propagate, like the reference
+        return seed[:, None].clone(), torch.zeros(N, 0), None
     xent = crw_hip.xent_metric(feats)
     change_idx = change_point(xent)
-    seed = seed_labels(seg_ref.to(feats.device), N)
     if hasattr(lp, 'propagate_all'):
         pred, _ = lp.propagate_all(feats, seed, nclasses)
     else:  # foreign label-propagation object: reference's frame-by-frame protocol

@@ -16,6 +16,12 @@ How the reference is made to run here:
   * the reference hard-codes ``'cuda'``; those spots are redirected to CPU:
     ``model.zeros`` (src/model.py:36), ``Tensor.cuda``, ``Tensor.to('cuda')``,
     ``torch.zeros(device='cuda')`` (src/utils.py:90,119,137,141,143; labelprop.py:103).
+  * the whole-radargram pipeline (``segment_*`` fixtures) runs the reference's own driver,
+    ``scripts/test/test_all.py`` ``main(args)``, imported from /root/reference with its private-data
+    factories (``create_dataset`` / ``get_reference`` / ``create_model`` / ``load``) pointed at
+    synthetic tensors, plotting and the sklearn reports turned into recorders, and -- because PELT
+    is unavailable -- ``propagate`` wrapped so that a chosen change index comes back for chosen
+    radargrams (everything else, including the correction / reverse / merge logic, is the reference's).
   * ``model.cross_entropy`` is wrapped with a recorder so every per-cycle transition product
     ``At_k`` (src/model.py:45) is captured -- the scalar loss alone is a weak parity probe.
 
@@ -55,11 +61,19 @@ def _install_placeholders():
                 out = TF.interpolate(img[None].float(), size=self.size, mode="nearest")[0]
                 return out.to(img.dtype)
 
+        fn = types.ModuleType("torchvision.transforms.functional")
+
+        def resize(img, size, interpolation=None):
+            return Resize(size)(img)
+
+        fn.resize = resize
         tr.InterpolationMode = InterpolationMode
         tr.Resize = Resize
+        tr.functional = fn
         tv.transforms = tr
         sys.modules["torchvision"] = tv
         sys.modules["torchvision.transforms"] = tr
+        sys.modules["torchvision.transforms.functional"] = fn
 
 
 def import_reference():
@@ -259,6 +273,128 @@ def run_labelprop_case(ref_utils, ref_lp, name, T, N, C, M, cfg, use_last, seed,
           f"label changes along-track={moved} change_idx={change_idx}")
 
 
+def layered_segmentation(rows, cols, M, gen, wiggle=3.0):
+    """[rows, cols] class ids: M sub-horizontal bands whose interfaces undulate along-track."""
+    c = torch.arange(cols).float()
+    out = torch.zeros(rows, cols)
+    for k in range(1, M):
+        edge = rows * k / M + wiggle * torch.sin(2 * np.pi * c / (37.0 + 11 * k) + k)
+        out += (torch.arange(rows).float()[:, None] >= edge[None, :]).float()
+    return out
+
+
+def run_segment_case(ref_dataset, name, dataset_id, nclasses, T, hw, oh, H_rg, n_rg, seg_rows_extra, cfg, use_last,
+                     correction, forced_change, seed):
+    """scripts/test/test_all.py main(args) of the reference on synthetic data -> forward (+corrected) int8 map that
+    the script saves (`predicted_map.pt`, test_all.py:128) and the final map after the reversed-pass merge
+    (test_all.py:132-159, what its report is computed on)."""
+    import importlib
+    import tempfile
+    import argparse
+    sys.path.insert(0, os.path.join(REF, "scripts", "test"))
+    import test_all as ref_main
+    importlib.reload(ref_main)
+    gen = torch.Generator().manual_seed(seed)
+    h, w = hw
+    W_rg = n_rg * T * w
+    # patch pixels ARE the features (PatchFlatten): a layered medium so that labels must follow the layers
+    r = torch.arange(H_rg).float()[:, None]
+    c = torch.arange(W_rg).float()[None, :]
+    rg = (torch.sin(2 * np.pi * (r + 2.5 * torch.sin(2 * np.pi * c / 61.0)) / 9.0) + 0.5 * torch.cos(0.37 * r + 0.011 * c)
+          + 0.25 * torch.randn(H_rg, W_rg, generator=gen)).float()
+    N = (H_rg - oh) // (h - oh)
+    seg_full = layered_segmentation(H_rg + seg_rows_extra, W_rg, nclasses, gen)
+    saved, reports = {}, {}
+    tmp = tempfile.mkdtemp()
+    torch.save(rg, os.path.join(tmp, "rg.pt"))
+
+    def create_dataset(id, length, dim, overlap, full=False, flip=False):
+        return ref_dataset.RGDataset(filepath=os.path.join(tmp, "rg.pt"), length=length, dim=dim, overlap=overlap, flip=flip)
+
+    def get_reference(id, h, w, flip=False, length=None, dim=None, overlap=None):
+        return nclasses, seg_full[:h, :].clone()
+
+    calls = {"n": 0}
+    orig_propagate = ref_main.propagate
+
+    def propagate(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last):
+        pred, xent, change = orig_propagate(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last=use_last)
+        i = calls["n"]
+        calls["n"] += 1
+        if forced_change is not None and i < len(forced_change):
+            change = forced_change[i]
+        return pred, xent, change
+
+    ref_main.create_dataset = create_dataset
+    ref_main.get_reference = get_reference
+    ref_main.create_model = lambda id, pos_embed: PatchFlatten()
+    ref_main.load = lambda path: {}
+    ref_main.plot = lambda **k: None
+    ref_main.propagate = propagate
+    ref_main.device_count = lambda: 1
+    ref_main.classification_report = lambda gt, pred: reports.update(gt=gt.clone(), pred=pred.clone()) or ""
+    ref_main.confusion_matrix = lambda gt, pred: ""
+    _save = torch.save
+    ref_main.torch.save = lambda obj, path: saved.update(map=obj.clone())
+    args = argparse.Namespace(model=0, dataset=dataset_id, patch_size=hw, seq_length=T, overlap=(oh, 0),
+                              cxt_size=cfg["CXT_SIZE"], radius=cfg["RADIUS"], temp=cfg["TEMP"], knn=cfg["KNN"],
+                              model_path="", output_folder=tmp + "/", pos_embed=False, remove_unc=False, flip=False,
+                              use_last=use_last, dataset_full=True, correction=correction)
+    try:
+        with cuda_is_cpu():
+            ref_main.main(args)
+    finally:
+        torch.save = _save
+    rows = saved["map"].shape[0]
+    final = reports["pred"].reshape(rows, -1)
+    np.savez(os.path.join(HERE, name + ".npz"), rg=rg.numpy(), seg=seg_full.numpy(), dataset_id=np.int32(dataset_id),
+             nclasses=np.int32(nclasses), T=np.int32(T), patch=np.int32(hw), overlap=np.int32((oh, 0)),
+             cxt_size=np.int32(cfg["CXT_SIZE"]), radius=np.int32(cfg["RADIUS"]), temp=np.float32(cfg["TEMP"]),
+             knn=np.int32(cfg["KNN"]), use_last=np.bool_(use_last), correction=np.bool_(correction),
+             forced_change=np.int32([-1 if f is None else f for f in (forced_change or [])]),
+             saved_map=saved["map"].numpy(), final_map=final.numpy().astype(np.int8))
+    changed = int((final.to(torch.int8) != saved["map"]).sum())
+    print(f"{name}: N={N} map{tuple(saved['map'].shape)} classes={sorted(set(final.flatten().tolist()))} "
+          f"pixels changed by the reverse merge={changed}")
+
+
+def run_resnet_train_case(ref_model, ref_encoder, name, B, T, N, tau, seed):
+    """Reference CRW with its default encoder (Resnet, BatchNorm in train mode) on CPU: loss, A, features, a selection of
+    parameter gradients (+ the norm of every gradient) and the BatchNorm running statistics after the step."""
+    torch.manual_seed(seed)
+    enc = ref_encoder.Resnet(False)
+    enc.train(True)
+    gen = torch.Generator().manual_seed(seed)
+    oh = 8
+    rg = layered_radargram(N * 8 + oh, 2 * T * 16, gen)
+    seq = torch.stack([unfold_items(rg, T, 16, 16, oh, 0, i * T) for i in range(B)])
+    crw = ref_model.CRW(enc, tau, False)
+    feats = {}
+    hook = enc.register_forward_hook(lambda m, i, o: feats.__setitem__("emb", o.detach().clone()))
+    with cuda_is_cpu():
+        loss, A = crw(seq)
+    hook.remove()
+    loss.backward()
+    out = dict(seq=seq.numpy(), tau=np.float32(tau), seed=np.int32(seed), emb=feats["emb"].numpy(), A=A.detach().numpy(),
+               loss=loss.detach().numpy())
+    keep = ("fc0.weight", "bn0.weight", "model.conv1.weight", "model.layer1.0.conv1.weight", "model.layer2.0.downsample.0.weight",
+            "model.layer4.0.bn2.bias", "model.fc.weight", "model.fc.bias")
+    names, norms = [], []
+    for k, p in enc.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k in keep:
+            out["grad." + k] = p.grad.numpy()
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms)
+    out["bn0.running_mean"] = enc.bn0.running_mean.numpy()
+    out["bn0.running_var"] = enc.bn0.running_var.numpy()
+    out["model.bn1.running_mean"] = enc.model.bn1.running_mean.numpy()
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: loss={float(loss):.7f} seq{tuple(seq.shape)} {len(names)} parameter tensors")
+
+
+
 def run_dataset_case(ref_dataset, name, H, W, length, dim, overlap, seed):
     import tempfile
     gen = torch.Generator().manual_seed(seed)
@@ -315,6 +451,16 @@ def main():
     run_labelprop_case(ref_utils, ref_lp, "labelprop_mc1_T100N12", 100, 12, 32, 4,
                        dict(CXT_SIZE=80, RADIUS=10, TEMP=0.01, KNN=10), False, 34)
     run_resnet_case(ref_encoder, "resnet_seed11", 11)
+    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_B2T4N5", 2, 4, 5, 0.05, 11)
+    # whole-radargram pipeline through the reference's own driver (scripts/test/test_all.py main)
+    lpc = dict(CXT_SIZE=4, RADIUS=4, TEMP=0.1, KNN=5)
+    run_segment_case(ref_dataset, "segment_ds0_reverse", 0, 4, 8, (8, 8), 4, 52, 3, 2, lpc, True, False, None, 51)
+    run_segment_case(ref_dataset, "segment_ds1_reverse", 1, 6, 8, (8, 8), 4, 52, 3, 2, lpc, True, False, None, 52)
+    run_segment_case(ref_dataset, "segment_ds3_reverse", 3, 5, 8, (8, 8), 4, 52, 3, 2, lpc, True, False, None, 53)
+    run_segment_case(ref_dataset, "segment_ds0_correction", 0, 4, 8, (8, 8), 4, 52, 3, 2, lpc, False, True,
+                     [3, None, 7], 54)
+    run_segment_case(ref_dataset, "segment_ds3_correction_reverse", 3, 5, 8, (8, 8), 4, 52, 3, 2, lpc, True, True,
+                     [None, 5, None], 55)
     # dataset unfold
     run_dataset_case(ref_dataset, "dataset_64x256", 64, 256, 8, (16, 16), (8, 0), 41)
     run_dataset_case(ref_dataset, "dataset_50x200_ow", 50, 200, 5, (12, 10), (4, 2), 42)

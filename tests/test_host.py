@@ -173,3 +173,95 @@ def test_pelt_rbf_restatement():
     ci = crw_utils.change_point(xent)
     assert ci is not None and ci >= 5
     assert crw_utils.change_point(torch.zeros(4, 30)) is None
+
+
+SEGMENT_CASES = ["segment_ds0_reverse", "segment_ds1_reverse", "segment_ds3_reverse", "segment_ds0_correction",
+                 "segment_ds3_correction_reverse"]
+
+
+def run_segment_golden(g, propagate_fn, device):
+    """Drive ``inference.segment`` on the inputs of a ``segment_*`` fixture (written by the reference's own
+    scripts/test/test_all.py main(args)); ``propagate_fn`` stands in for ``utils.propagate`` (the CPU tests put the
+    oracle there, the GPU tests the real HIP path) and is wrapped to force the fixture's change indices, exactly
+    like the generator wrapped the reference's ``propagate``."""
+    import dataset as crw_dataset
+    import inference as crw_inference
+    from imported.labelprop import LabelPropVOS_CRW
+    T, patch, overlap = int(g["T"]), tuple(int(v) for v in g["patch"]), tuple(int(v) for v in g["overlap"])
+    ds = crw_dataset.RGDataset.from_tensor(torch.tensor(g["rg"]), T, patch, overlap)
+    N = ds[0].shape[1]
+    seg = torch.tensor(g["seg"])[:N * patch[0]]           # get_reference(h = N*H) (test_all.py:60)
+    forced = [None if f < 0 else int(f) for f in g["forced_change"]]
+    calls = {"n": 0}
+
+    def propagate(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last):
+        pred, xent, change = propagate_fn(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last)
+        i = calls["n"]
+        calls["n"] += 1
+        if i < len(forced):
+            change = forced[i]
+        return pred, xent, change
+
+    class Flatten(torch.nn.Module):
+        def forward(self, x):
+            return x.flatten(1)
+
+    cfg = dict(CXT_SIZE=int(g["cxt_size"]), RADIUS=int(g["radius"]), TEMP=float(g["temp"]), KNN=int(g["knn"]))
+    orig = crw_inference.propagate
+    crw_inference.propagate = propagate
+    try:
+        out = crw_inference.segment(ds, seg, Flatten(), LabelPropVOS_CRW(cfg), int(g["nclasses"]), T, patch, overlap,
+                                    correction=bool(g["correction"]), use_last=bool(g["use_last"]),
+                                    dataset_id=int(g["dataset_id"]), device=device)
+    finally:
+        crw_inference.propagate = orig
+    return out
+
+
+@pytest.mark.parametrize("name", SEGMENT_CASES)
+def test_segment_driver_matches_reference_main(name):
+    """Host logic of the whole-radargram pipeline (forward, correction with the reference's `get_smaller_item`
+    semantics, reverse pass, per-dataset merge rules) against maps produced by the reference's scripts/test/test_all.py
+    main(args); label propagation itself is the CPU oracle here (the GPU twin of this test runs the HIP kernels)."""
+    g = load_golden(name)
+
+    def oracle_propagate(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last):
+        T, N = seq.shape[:2]
+        emb = model(seq.reshape(T * N, 1, *seq.shape[2:])).reshape(T, N, -1).numpy()
+        if use_last:
+            emb = emb[::-1].copy()
+        pred = orc.labelprop(emb, orc.seed_labels(seg_ref.numpy(), N), ncls, lp.cxt_size, lp.radius, lp.temperature, lp.topk)
+        return torch.tensor(pred), torch.tensor(orc.xent_metric(emb)), None
+
+    out = run_segment_golden(g, oracle_propagate, "cpu")
+    assert np.array_equal(out["forward"].numpy().astype(np.int8), g["saved_map"])
+    assert np.array_equal(out["pred"].numpy().astype(np.int8), g["final_map"])
+    if bool(g["correction"]):
+        assert any(f >= 0 for f in g["forced_change"])
+
+
+def test_resnet_train_mode_matches_reference_on_cpu():
+    """`Resnet` (the reference's default encoder) in train mode: features, BatchNorm running statistics and -- through the
+    oracle's walk -- loss and parameter gradients against the reference's CRW forward/backward (fixture resnet_train_*)."""
+    import encoder as crw_encoder
+    g = load_golden("resnet_train_B2T4N5")
+    torch.manual_seed(int(g["seed"]))
+    enc = crw_encoder.Resnet(False)
+    enc.train(True)
+    seq = torch.tensor(g["seq"])
+    B, T, N, h, w = seq.shape
+    emb = enc(seq.reshape(-1, h, w).unsqueeze(1))
+    np.testing.assert_allclose(emb.detach().numpy(), g["emb"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(enc.bn0.running_mean.numpy(), g["bn0.running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(enc.bn0.running_var.numpy(), g["bn0.running_var"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(enc.model.bn1.running_mean.numpy(), g["model.bn1.running_mean"], rtol=1e-4, atol=1e-6)
+    loss, A = orc.walk_loss_torch(emb.reshape(B, T, N, -1), float(g["tau"]))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5
+    np.testing.assert_allclose(A.detach().numpy(), g["A"], rtol=1e-3, atol=1e-3)
+    loss.backward()
+    names = [k for k, _ in enc.named_parameters()]
+    assert names == list(g["grad_names"])
+    for k, p in enc.named_parameters():
+        if "grad." + k in g:
+            ref = g["grad." + k]
+            np.testing.assert_allclose(p.grad.numpy(), ref, rtol=5e-3, atol=5e-4 * np.abs(ref).max())
