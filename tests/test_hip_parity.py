@@ -697,7 +697,8 @@ def test_resnet_training_step_matches_reference(hip):
     assert names == list(g["grad_names"])
     for (k, p_), ref_norm in zip(enc.named_parameters(), g["grad_norms"]):
         got = float(p_.grad.double().norm())
-        assert abs(got - ref_norm) <= 2e-2 * ref_norm + 1e-7, (k, got, ref_norm)
+        # (fc0.bias feeds a BatchNorm: its true gradient is zero, both sides hold rounding noise ~1e-6)
+        assert abs(got - ref_norm) <= 2e-2 * ref_norm + 1e-4, (k, got, ref_norm)
         if "grad." + k in g:
             ref = g["grad." + k]
             np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max())
