@@ -631,7 +631,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
   f32x4 accb[NCOW];
 #pragma unroll
   for (int j = 0; j < NCOW; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool bias_wave = grp_ci == 0 && wci == 0;  // wave-uniform
+  // scalar condition (readfirstlane): matrix instructions ignore EXEC, so a block holding them must be branched around
+  const bool bias_wave = grp_ci == 0 && __builtin_amdgcn_readfirstlane(wci) == 0;
 
   const int p_begin = wg_slice * a.patches_per_block;
   const int p_end = min(a.P, p_begin + a.patches_per_block);
@@ -880,6 +881,240 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, second generation ("streamed"): ONE workgroup of 8 waves per CU, two waves per SIMD that both
+// compute all the time (tools/ubench/wgrad_kstep.hip: this wave arrangement keeps the matrix pipe as busy as a loop
+// without any LDS read, where a lone wave per SIMD loses 10-12 % and the two-workgroup arrangement above loses each
+// workgroup's load phase).  Workgroup tile = 9 taps x 128 output x 64 input channels, wave tile = 4 co x 1 ci x 9 taps.
+//   * The reduction runs over the pixel STREAM of a patch slice (pixel G = 100 * patch + pixel, contiguous in the dY
+//     planes): k-step n takes stream pixels [32 n, 32 n + 32), whatever patches they belong to -- no per-patch
+//     padding, no tail strips.
+//   * dY lives in LDS one k-step at a time (two ring slots of 32 rows), X as whole 12x12 patch images in two slots
+//     (patch q in slot q & 1); a k-step that straddles two patches reads both slots (per-lane slot choice).
+//   * Loads are register-staged one k-step ahead: at the top of k-step n every thread issues its global loads for
+//     k-step n + 1 (32 dY rows; and, where a new patch begins at k-step n + 2 / n + 1, the hi / lo plane of its X
+//     image), computes k-step n, then stores the staged registers to LDS; ONE barrier per k-step.  A slot is only
+//     written a full k-step after its last reader (see the schedule in the kernel).
+//   * Rows of a k-step are dealt to the lane groups by parity (half-wave 0: even rows, half-wave 1: odd rows): on the
+//     2C+16 row stride eight same-parity rows start in eight different bank octets (consecutive rows collide 2-way).
+constexpr int W2_NCO = 128, W2_NCI = 64, W2_NW = 8, W2_KROWS = 32;
+
+template <int SPLIT, int CIN, int COUT>
+__global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
+  constexpr int NCO = W2_NCO, NCI = W2_NCI, NTH = W2_NW * 64, NPL = (SPLIT == 3) ? 2 : 1;
+  constexpr int XS = row_stride<NCI>(), XPL = NPAD * XS, XSLOT = NPL * XPL;     // X: 12x12 padded image per plane
+  constexpr int YS = row_stride<NCO>(), YPL = W2_KROWS * YS, YSLOT = NPL * YPL; // dY: 32 rows per plane
+  constexpr int NCOW = 4, WCI = 4;                                              // wave tile: 4 co tiles x 1 ci tile
+  static_assert(COUT == NCO && CIN % NCI == 0, "tiling");
+  constexpr int NGRP = CIN / NCI;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char *xs = lds, *ys = lds + 2 * XSLOT;
+
+  // workgroup id -> (slice, ci group): the groups of a slice sit on one XCD (ids L and L + 8), see the kernel above
+  const int wg_slice = a.xcd_map ? ((int)blockIdx.x / 8 / NGRP) * 8 + (int)blockIdx.x % 8 : (int)blockIdx.x / NGRP;
+  const int grp_ci = a.xcd_map ? ((int)blockIdx.x / 8) % NGRP : (int)blockIdx.x % NGRP;
+  const int ci_base = grp_ci * NCI;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int wci = wave % WCI, wco = wave / WCI;
+  const int wci_s = __builtin_amdgcn_readfirstlane(wci);  // provably wave-uniform copy for scalar branches
+  const int co0w = wco * NCOW * 16;
+
+  const int p_begin = wg_slice * a.patches_per_block;
+  const int np = min(a.P, p_begin + a.patches_per_block) - p_begin;  // patches of this slice (>= 1 by construction)
+  const int npx = np * NPIX;                                         // pixels of the stream
+  const int NK = (npx + W2_KROWS - 1) / W2_KROWS;
+
+  f32x4 acc[9][NCOW];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < NCOW; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};  // bias gradient of co tile `wci` of this wave's co half (ci group 0 only)
+  const bool bias_wg = grp_ci == 0;        // workgroup-uniform
+
+  // zero both X slots once (the halo stays zero: only interior pixels are ever written)
+  for (int c = tid; c < 2 * XSLOT / 16; c += NTH) *reinterpret_cast<uint4 *>(xs + 16 * c) = uint4{0, 0, 0, 0};
+
+  // ---- staging: what a thread loads / stores ----------------------------------------------------------------
+  // dY of a k-step: 32 rows x 16 chunks (8 channels) = 512 chunks = one per thread and plane
+  const int yrow = tid >> 4, ych = tid & 15;
+  // X plane of a patch: 100 pixels x 8 chunks = 800 chunks: threads take chunk tid and tid + 512
+  constexpr int XCH = NCI / 8, XTOT = NPIX * XCH;
+  // Global loads go through buffer descriptors rooted at the slice (scalar base + 32-bit per-thread offset: no 64-bit
+  // address registers are kept alive across the k-loop, and a row past the end of the stream reads as zero)
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  const long dy_off = (long)p_begin * NPIX * COUT, x_off = (long)p_begin * NPIX * CIN + ci_base;
+  const __amdgpu_buffer_rsrc_t dyh_rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dyh + dy_off), 0, npx * COUT * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)((SPLIT == 3 && !a.dgap ? a.dyl : a.dyh) + dy_off), 0, npx * COUT * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xh_rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xh + x_off), 0, (npx * CIN - ci_base) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xl_rs = __builtin_amdgcn_make_buffer_rsrc((void *)((SPLIT == 3 ? a.xl : a.xh) + x_off), 0,
+                                                                          (npx * CIN - ci_base) * 2, 0x00020000);
+  const int y_voff = (yrow * COUT + 8 * ych) * 2;
+  int x_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = min(tid + i * NTH, XTOT - 1);
+    x_voff[i] = ((c / XCH) * CIN + 8 * (c % XCH)) * 2;
+  }
+  uint4 sy[NPL], sx[2];
+  auto load_dy = [&](int n) {  // the 32 rows of k-step n; rows past the stream are out of the descriptor's range: zeros
+    const int soff = n * (W2_KROWS * COUT * 2);
+    sy[0] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(dyh_rs, y_voff, soff, 0));
+    if (SPLIT == 3 && !a.dgap) sy[NPL - 1] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(dyl_rs, y_voff, soff, 0));
+  };
+  auto store_dy = [&](int n) {
+    uint4 vh = sy[0], vl = uint4{0, 0, 0, 0};
+    if (SPLIT == 3 && !a.dgap) vl = sy[NPL - 1];
+    if (a.dgap) {  // fused ReLU + GAP backward: dY = dgap / 100 where the forward activation (sy[0]) is non-zero
+      const int G = 32 * n + yrow;  // (rows past the stream loaded zero activations: their dY is zero whatever dgap row is read)
+      uint32_t gh[4], gl[4];
+      gap_split8(a.dgap + (long)(p_begin + min(G, npx - 1) / NPIX) * COUT + 8 * ych, gh, gl);
+      gap_mask8(sy[0], gh, gl, vh, vl);
+    }
+    char *dst = ys + (n & 1) * YSLOT + yrow * YS + 16 * ych;
+    *reinterpret_cast<uint4 *>(dst) = vh;
+    if (SPLIT == 3) *reinterpret_cast<uint4 *>(dst + YPL) = vl;
+  };
+  auto load_x = [&](int q, int pl) {  // plane pl of patch q of the slice
+    const int soff = q * (NPIX * CIN * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      sx[i] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(pl ? xl_rs : xh_rs, x_voff[i], soff, 0));
+  };
+  auto store_x = [&](int q, int pl) {
+    char *dst = xs + (q & 1) * XSLOT + pl * XPL;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * NTH;
+      if (c < XTOT) *reinterpret_cast<uint4 *>(dst + interior_pp(c / XCH) * XS + 16 * (c % XCH)) = sx[i];
+    }
+  };
+  // first k-step that touches patch q
+  auto first_k = [&](int q) { return (q * NPIX) / W2_KROWS; };
+  // patch whose first k-step is n, or -1
+  auto patch_starting_at = [&](int n) {
+    if (n >= NK) return -1;
+    const int q = min((32 * n + 31) / NPIX, np - 1);  // patch of the last stream pixel of k-step n
+    return first_k(q) == n ? q : -1;
+  };
+
+  // ---- fragment addressing -------------------------------------------------------------------------------------
+  const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
+  const int t16 = lane & 15, q4 = t16 >> 2, pq = t16 & 3;
+  const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
+  // parity order: lane group g, fragment row q4 -> k-step row 2 (4 (g & 1) + q4) + (g >> 1)  (+16 for the second read)
+  const int r_lo = 2 * (4 * (g & 1) + q4) + (g >> 1), r_hi = r_lo + 16;
+  const uint32_t ya_lo0 = ys_a + r_lo * YS + lane_col + 2 * co0w, ya_hi0 = ys_a + r_hi * YS + lane_col + 2 * co0w;
+  auto x_addr = [&](int G) {  // tap-(0,0) source pixel of stream pixel G in its patch slot
+    const int Gc = min(G, npx - 1);  // rows past the stream multiply zero dY rows: any valid address
+    const int q = Gc / NPIX, i = Gc - q * NPIX;
+    return xs_a + (q & 1) * XSLOT + ((i / IMG_W) * PAD_W + (i % IMG_W)) * XS + lane_col + 32 * wci;
+  };
+
+  auto kstep = [&](int n) {
+    const uint32_t ya_lo = ya_lo0 + (n & 1) * YSLOT, ya_hi = ya_hi0 + (n & 1) * YSLOT;
+    const uint32_t xa_lo = x_addr(32 * n + r_lo), xa_hi = x_addr(32 * n + r_hi);
+    bf8 ah[NCOW], al[NCOW];
+    static_for<NCOW>([&](auto JC) {
+      constexpr int j = decltype(JC)::value;
+      ah[j] = tr_frag<32 * j>(ya_lo, ya_hi);
+      if (SPLIT == 3) al[j] = tr_frag<YPL + 32 * j>(ya_lo, ya_hi);
+    });
+    bf8 bh[2], bl[2];
+    auto read_b = [&](auto TC) {
+      constexpr int tap = decltype(TC)::value;
+      constexpr int XO = ((tap / 3) * PAD_W + (tap % 3)) * XS;
+      bh[tap & 1] = tr_frag<XO>(xa_lo, xa_hi);
+      if (SPLIT == 3) bl[tap & 1] = tr_frag<XPL + XO>(xa_lo, xa_hi);
+    };
+    read_b(std::integral_constant<int, 0>{});
+    static_for<9>([&](auto TC) {
+      constexpr int tap = decltype(TC)::value;
+      if constexpr (tap < 8) {
+        read_b(std::integral_constant<int, tap + 1>{});
+        if (SPLIT == 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (tap == 0) {
+        if (bias_wg) {  // one co tile per wave (wave-uniform choice, static fragment index)
+          const s8v o = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};  // bf16 1.0
+          const bf8 ones = __builtin_bit_cast(bf8, o);
+          // wci_s is a SCALAR (readfirstlane): with a per-lane condition hipcc predicates the block through EXEC, and the
+          // matrix instructions ignore EXEC -- every wave would add all four tiles
+          static_for<NCOW>([&](auto JC) {
+            constexpr int j = decltype(JC)::value;
+            if (wci_s == j) {
+              if (SPLIT == 3) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], ones, accb, 0, 0, 0);
+              accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], ones, accb, 0, 0, 0);
+            }
+          });
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NCOW; ++j) {
+        if (SPLIT == 3) {
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl[tap & 1], acc[tap][j], 0, 0, 0);
+        }
+        acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh[tap & 1], acc[tap][j], 0, 0, 0);
+      }
+    });
+  };
+
+  // ---- prologue: patch 0 and k-step 0 --------------------------------------------------------------------------
+  load_dy(0);
+  load_x(0, 0);
+  __syncthreads();  // (the zero fill above is complete)
+  store_x(0, 0);
+  if (SPLIT == 3) {
+    load_x(0, 1);
+    store_x(0, 1);
+  }
+  store_dy(0);
+  __syncthreads();
+
+  // ---- main loop ---------------------------------------------------------------------------------------------
+  // k-step n: issue the loads for k-step n + 1 (dY; X hi plane of the patch that starts at n + 2, X lo plane -- or the only
+  // plane -- of the patch that starts at n + 1), compute, store the staged registers, barrier.
+  // Slot safety: patch q (first k-step F) is stored at the end of k-steps F - 2 (hi) / F - 1 (lo); the patch q - 2 that
+  // occupied the slot was last read in k-step <= F - 3 (its last pixel is 100 (q - 1) - 1, and 100 q / 32 - (100 q - 101) / 32 > 3).
+#pragma unroll 1
+  for (int n = 0; n < NK; ++n) {
+    const bool more = n + 1 < NK;
+    const int q_hi = (SPLIT == 3) ? patch_starting_at(n + 2) : -1;  // wave-uniform
+    const int q_lo = patch_starting_at(n + 1);
+    // (a patch starts every 3.125 k-steps: q_hi and q_lo are never both set)
+    const int xq = q_lo >= 0 ? q_lo : q_hi, xpl = q_lo >= 0 ? NPL - 1 : 0;
+    // the loads are UNCONDITIONAL (clamped): a load under a run-time condition makes hipcc wait for it on the spot (the
+    // value is merged with the not-taken path), which would serialise a memory round trip into every k-step
+    load_dy(more ? n + 1 : n);
+    load_x(xq >= 0 ? xq : 0, xpl);
+    kstep(n);
+    if (more) store_dy(n + 1);
+    if (xq >= 0) store_x(xq, xpl);
+    __syncthreads();
+  }
+
+  float *dwp = a.dw_part + (long)wg_slice * COUT * CIN * 9;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int j = 0; j < NCOW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0w + 16 * j + 4 * g + r, ci = ci_base + 16 * wci + (lane & 15);
+        dwp[((long)tap * COUT + co) * CIN + ci] = acc[tap][j][r];
+      }
+  if (bias_wg && (lane & 15) == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.db_part[(long)wg_slice * COUT + co0w + 16 * wci + 4 * g + r] = accb[r];
+  }
+}
+
 // out[e] = sum over slices of part[s][e]   (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void slice_sum_kernel(const float *__restrict__ part, int nslice, long n,
                                                         float *__restrict__ out) {
@@ -1057,6 +1292,23 @@ int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
   return check_launch();
 }
 
+template <int SPLIT, int CIN, int COUT>
+int launch_wgrad2(const WgradArgs &a, int nslice, hipStream_t s) {
+  constexpr int NPL = SPLIT == 3 ? 2 : 1;
+  const size_t lds = (size_t)2 * NPL * (NPAD * row_stride<W2_NCI>() + W2_KROWS * row_stride<W2_NCO>());
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void *)conv3x3_wgrad2_kernel<SPLIT, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv3x3_wgrad2_kernel<SPLIT, CIN, COUT>), dim3(nslice * (CIN / W2_NCI)), dim3(W2_NW * 64), lds, s, a);
+  return check_launch();
+}
+
 inline int ew_grid(long n) {
   long b = (n + 255) / 256;
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -1177,17 +1429,31 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   if (split == 3 && ((!dy_lo && !dgap) || !x_lo)) return CRW_EINVAL;
   if (ws_bytes < crw_enc_wgrad_ws_bytes(P, cin, cout, split)) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int nslice = wgrad_slices(P, cin, cout, split);
-  const int ppb = (P + nslice - 1) / nslice;
+  int nslice = wgrad_slices(P, cin, cout, split);
+  // the streamed kernel (one 8-wave workgroup per CU) for the layers with 128 output channels; CRW_WGRAD=1 forces the
+  // first-generation kernel (diagnostics / A-B)
+  static const char *force = getenv("CRW_WGRAD");
+  const bool streamed = cout == W2_NCO && cin % W2_NCI == 0 && !(force && force[0] == '1');
+  if (streamed) {
+    const int n2 = 256 / (cin / W2_NCI);
+    nslice = n2 > P ? P : n2;
+  }
+  int ppb = (P + nslice - 1) / nslice;
+  if (streamed) nslice = (P + ppb - 1) / ppb;  // no empty slices: every slab is written
   float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
   WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, nslice % 8 == 0 ? 1 : 0, g_conv_stamps};
   int st = CRW_EINVAL;
+  if (streamed) {
+    if (cin == 64) st = split == 3 ? launch_wgrad2<3, 64, 128>(a, nslice, s) : launch_wgrad2<1, 64, 128>(a, nslice, s);
+    else if (cin == 128) st = split == 3 ? launch_wgrad2<3, 128, 128>(a, nslice, s) : launch_wgrad2<1, 128, 128>(a, nslice, s);
+  } else {
 #define CRW_WG_CASE(CI, CO)                                                                  \
   if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);
   CRW_WG_CASE(32, 64)
   CRW_WG_CASE(64, 128)
   CRW_WG_CASE(128, 128)
 #undef CRW_WG_CASE
+  }
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
   const int nblk_dw = (int)((nw + 63) / 64);
