@@ -899,7 +899,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
 //     2C+16 row stride eight same-parity rows start in eight different bank octets (consecutive rows collide 2-way).
 constexpr int W2_NCO = 128, W2_NCI = 64, W2_NW = 8, W2_KROWS = 32;
 
-template <int SPLIT, int CIN, int COUT>
+// DIAG (timing-only diagnostic builds of the conv5 shape, CRW_WGRAD_DIAG=1|2|3; results are wrong): 1 = no barrier in the k-loop,
+// 2 = no staging (no global loads, no LDS stores), 3 = both -- what the k-loop costs without its pipeline partners
+template <int SPLIT, int CIN, int COUT, int DIAG = 0>
 __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
   constexpr int NCO = W2_NCO, NCI = W2_NCI, NTH = W2_NW * 64, NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int XS = row_stride<NCI>(), XPL = NPAD * XS, XSLOT = NPL * XPL;     // X: 12x12 padded image per plane
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
   constexpr int NGRP = CIN / NCI;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *xs = lds, *ys = lds + 2 * XSLOT;
+  char *gs = ys + 2 * YSLOT;  // dgap mode: [2 patch slots][hi, lo][128 channels] bf16 = dgap / 100 of the two resident patches
 
   // workgroup id -> (slice, ci group): the groups of a slice sit on one XCD (ids L and L + 8), see the kernel above
   const int wg_slice = a.xcd_map ? ((int)blockIdx.x / 8 / NGRP) * 8 + (int)blockIdx.x % 8 : (int)blockIdx.x / NGRP;
@@ -967,9 +970,12 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
     uint4 vh = sy[0], vl = uint4{0, 0, 0, 0};
     if (SPLIT == 3 && !a.dgap) vl = sy[NPL - 1];
     if (a.dgap) {  // fused ReLU + GAP backward: dY = dgap / 100 where the forward activation (sy[0]) is non-zero
-      const int G = 32 * n + yrow;  // (rows past the stream loaded zero activations: their dY is zero whatever dgap row is read)
-      uint32_t gh[4], gl[4];
-      gap_split8(a.dgap + (long)(p_begin + min(G, npx - 1) / NPIX) * COUT + 8 * ych, gh, gl);
+      // the split dgap row of the row's patch waits in LDS (stage_gap): no global round trip here.  Rows past the
+      // stream loaded zero activations: their dY is zero whatever slot is read.
+      const int q = (32 * n + yrow) / NPIX;
+      const uint4 h4 = *reinterpret_cast<const uint4 *>(gs + (q & 1) * (4 * COUT) + 16 * ych);
+      const uint4 l4 = *reinterpret_cast<const uint4 *>(gs + (q & 1) * (4 * COUT) + 2 * COUT + 16 * ych);
+      const uint32_t gh[4] = {h4.x, h4.y, h4.z, h4.w}, gl[4] = {l4.x, l4.y, l4.z, l4.w};
       gap_mask8(sy[0], gh, gl, vh, vl);
     }
     char *dst = ys + (n & 1) * YSLOT + yrow * YS + 16 * ych;
@@ -988,6 +994,15 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * NTH;
       if (c < XTOT) *reinterpret_cast<uint4 *>(dst + interior_pp(c / XCH) * XS + 16 * (c % XCH)) = sx[i];
+    }
+  };
+  // dgap mode: split dgap[patch q] / 100 into bf16 hi / lo once per patch (16 threads, 8 channels each) -> LDS strip
+  auto stage_gap = [&](int q) {
+    if (tid < COUT / 8) {
+      uint32_t gh[4], gl[4];
+      gap_split8(a.dgap + (long)(p_begin + q) * COUT + 8 * tid, gh, gl);
+      *reinterpret_cast<uint4 *>(gs + (q & 1) * (4 * COUT) + 16 * tid) = uint4{gh[0], gh[1], gh[2], gh[3]};
+      *reinterpret_cast<uint4 *>(gs + (q & 1) * (4 * COUT) + 2 * COUT + 16 * tid) = uint4{gl[0], gl[1], gl[2], gl[3]};
     }
   };
   // first k-step that touches patch q
@@ -1068,7 +1083,8 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
   // ---- prologue: patch 0 and k-step 0 --------------------------------------------------------------------------
   load_dy(0);
   load_x(0, 0);
-  __syncthreads();  // (the zero fill above is complete)
+  if (a.dgap) stage_gap(0);
+  __syncthreads();  // (the zero fill above is complete; patch 0's dgap strip is visible)
   store_x(0, 0);
   if (SPLIT == 3) {
     load_x(0, 1);
@@ -1085,18 +1101,29 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
 #pragma unroll 1
   for (int n = 0; n < NK; ++n) {
     const bool more = n + 1 < NK;
-    const int q_hi = (SPLIT == 3) ? patch_starting_at(n + 2) : -1;  // wave-uniform
+    const int q_2 = patch_starting_at(n + 2);                       // wave-uniform
+    const int q_hi = (SPLIT == 3) ? q_2 : -1;
     const int q_lo = patch_starting_at(n + 1);
     // (a patch starts every 3.125 k-steps: q_hi and q_lo are never both set)
     const int xq = q_lo >= 0 ? q_lo : q_hi, xpl = q_lo >= 0 ? NPL - 1 : 0;
     // the loads are UNCONDITIONAL (clamped): a load under a run-time condition makes hipcc wait for it on the spot (the
     // value is merged with the not-taken path), which would serialise a memory round trip into every k-step
-    load_dy(more ? n + 1 : n);
-    load_x(xq >= 0 ? xq : 0, xpl);
+    if (!(DIAG & 2)) {
+      load_dy(more ? n + 1 : n);
+      load_x(xq >= 0 ? xq : 0, xpl);
+    }
     kstep(n);
+    if (DIAG & 2) {
+      if (DIAG & 1) continue;
+      __syncthreads();
+      continue;
+    }
     if (more) store_dy(n + 1);
     if (xq >= 0) store_x(xq, xpl);
-    __syncthreads();
+    // the dgap strip of a patch is written two k-steps before its first pixel: its first reader is the store_dy at the end
+    // of the NEXT k-step (behind the barrier); the previous tenant of the slot (patch q - 2) ended >= 3 k-steps before
+    if (a.dgap && q_2 >= 0) stage_gap(q_2);
+    if (!(DIAG & 1)) __syncthreads();
   }
 
   float *dwp = a.dw_part + (long)wg_slice * COUT * CIN * 9;
@@ -1292,20 +1319,20 @@ int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
   return check_launch();
 }
 
-template <int SPLIT, int CIN, int COUT>
+template <int SPLIT, int CIN, int COUT, int DIAG = 0>
 int launch_wgrad2(const WgradArgs &a, int nslice, hipStream_t s) {
   constexpr int NPL = SPLIT == 3 ? 2 : 1;
-  const size_t lds = (size_t)2 * NPL * (NPAD * row_stride<W2_NCI>() + W2_KROWS * row_stride<W2_NCO>());
+  const size_t lds = (size_t)2 * NPL * (NPAD * row_stride<W2_NCI>() + W2_KROWS * row_stride<W2_NCO>()) + 2 * 4 * W2_NCO;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void *)conv3x3_wgrad2_kernel<SPLIT, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)conv3x3_wgrad2_kernel<SPLIT, CIN, COUT, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad2_kernel<SPLIT, CIN, COUT>), dim3(nslice * (CIN / W2_NCI)), dim3(W2_NW * 64), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_wgrad2_kernel<SPLIT, CIN, COUT, DIAG>), dim3(nslice * (CIN / W2_NCI)), dim3(W2_NW * 64), lds, s, a);
   return check_launch();
 }
 
@@ -1445,7 +1472,15 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   int st = CRW_EINVAL;
   if (streamed) {
     if (cin == 64) st = split == 3 ? launch_wgrad2<3, 64, 128>(a, nslice, s) : launch_wgrad2<1, 64, 128>(a, nslice, s);
-    else if (cin == 128) st = split == 3 ? launch_wgrad2<3, 128, 128>(a, nslice, s) : launch_wgrad2<1, 128, 128>(a, nslice, s);
+    else if (cin == 128) {
+#ifdef CRW_CONV_STAMPS
+      static const char *diag = getenv("CRW_WGRAD_DIAG");
+      if (diag && split == 3 && diag[0] == '1') return launch_wgrad2<3, 128, 128, 1>(a, nslice, s);
+      if (diag && split == 3 && diag[0] == '2') return launch_wgrad2<3, 128, 128, 2>(a, nslice, s);
+      if (diag && split == 3 && diag[0] == '3') return launch_wgrad2<3, 128, 128, 3>(a, nslice, s);
+#endif
+      st = split == 3 ? launch_wgrad2<3, 128, 128>(a, nslice, s) : launch_wgrad2<1, 128, 128>(a, nslice, s);
+    }
   } else {
 #define CRW_WG_CASE(CI, CO)                                                                  \
   if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad<3, CI, CO>(a, nslice, s) : launch_wgrad<1, CI, CO>(a, nslice, s);
