@@ -62,20 +62,25 @@ size_t crw_walk_scratch_bytes(int B, int T, int N, int chain);
 
 /* training path --------------------------------------------------------------------------- */
 /* emb [B,T,N,C] raw encoder output -> ehat [B,T,N,C] (L2-normalised, eps 1e-12),
- * norm [B,T,N] (= max(||e||, eps)), A [B,T-1,N,N] = ehat_t ehat_{t+1}^T / tau. */
+ * norm [B,T,N] (= max(||e||, eps)), A [B,T-1,N,N] = ehat_t ehat_{t+1}^T / tau.
+ * stats (may be NULL): [4][B][T-1][N] = row max, row sum exp, column max, column sum exp of every A[b,t] -- the
+ * statistics of the two softmaxes of src/model.py:44 (F = softmax(A), G = softmax(A^T)), produced in the epilogue of
+ * the affinity tiles so that crw_walk_fwd needs no pass over A to find them; needs ws of crw_affinity_ws_bytes. */
+size_t crw_affinity_ws_bytes(int B, int T, int N);
 int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau,
-                     float *ehat, float *norm, float *A, crw_stream_t stream);
+                     float *ehat, float *norm, float *A, float *stats, void *ws, size_t ws_bytes, crw_stream_t stream);
 
 /* A [B,T-1,N,N] -> loss[1] (= sum_k l_k / N, Appendix A.2 of SURVEY.md).
  * state: crw_walk_state_bytes(B,T,N) bytes, kept by the caller until crw_walk_bwd.
  * At_out: optional [B,T-2,N,N] copy of every per-cycle transition product (may be NULL).
  * chain: CRW_CHAIN_F32 | CRW_CHAIN_BF16 | CRW_CHAIN_BF16X3 (same value for fwd, bwd and the size
  * queries).   T < 3 -> loss = 0. */
-int crw_walk_fwd(const float *A, int B, int T, int N, int chain,
-                 void *state, size_t state_bytes, float *At_out, float *loss, crw_stream_t stream);
+int crw_walk_fwd(const float *A, const float *stats /* of crw_affinity_fwd, or NULL: computed here */, int B, int T, int N,
+                 int chain, void *state, size_t state_bytes, float *At_out, float *loss, crw_stream_t stream);
 
-/* gloss[1] (device scalar, dL/dloss) + state -> dA [B,T-1,N,N]. */
-int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain,
+/* gloss[1] (device scalar, dL/dloss) + the logits A the forward ran on + state -> dA [B,T-1,N,N]
+ * (the two softmaxes are recomputed from A and the statistics kept in `state`: half the bytes of storing them). */
+int crw_walk_bwd(const float *gloss, const float *A, int B, int T, int N, int chain,
                  void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
                  float *dA, crw_stream_t stream);
 

@@ -27,9 +27,10 @@ SIGNATURES = {
     "crw_padded_nodes": (_c_int, [_c_int, _c_int]),
     "crw_walk_state_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "crw_walk_scratch_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
-    "crw_affinity_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p, _p]),
-    "crw_walk_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _p, _p]),
-    "crw_walk_bwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _c_sz, _p, _p]),
+    "crw_affinity_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_affinity_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p, _p, _p, _c_sz, _p]),
+    "crw_walk_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _p, _p]),
+    "crw_walk_bwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _p, _c_sz, _p, _p]),
     "crw_affinity_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p]),
     "crw_normalize": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_topk": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _p, _p, _p]),
@@ -117,15 +118,23 @@ def padded_nodes(N, chain=CHAIN_F32):
 
 
 # ------------------------------------------------------------------------------ training path
-def affinity_fwd(emb, tau):
-    """emb [B,T,N,C] -> (A [B,T-1,N,N], ehat, norm)."""
+def affinity_fwd(emb, tau, want_stats=True):
+    """emb [B,T,N,C] -> (A [B,T-1,N,N], ehat, norm, stats [4,B,T-1,N] | None).  stats = row max / row sum exp / column max /
+    column sum exp of every A[b,t], from the epilogue of the affinity tiles (walk_fwd then needs no pass over A for them)."""
     B, T, N, C = emb.shape
     ehat = torch.empty_like(emb)
     norm = torch.empty(B, T, N, device=emb.device, dtype=torch.float32)
     A = torch.empty(B, T - 1, N, N, device=emb.device, dtype=torch.float32)
+    stats = ws = None
+    nbytes = 0
+    if want_stats and T > 1:
+        stats = torch.empty(4, B, T - 1, N, device=emb.device, dtype=torch.float32)
+        nbytes = lib().crw_affinity_ws_bytes(B, T, N)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=emb.device)
     _check(lib().crw_affinity_fwd(_dev(emb, "emb"), B, T, N, C, float(tau), _dev(ehat, "ehat"), _dev(norm, "norm"),
-                                  _dev(A, "A"), _stream()), "crw_affinity_fwd")
-    return A, ehat, norm
+                                  _dev(A, "A"), _dev(stats, "stats") if stats is not None else None,
+                                  ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, nbytes, _stream()), "crw_affinity_fwd")
+    return A, ehat, norm, stats
 
 
 def affinity_bwd(dA, ehat, norm, tau):
@@ -137,26 +146,32 @@ def affinity_bwd(dA, ehat, norm, tau):
     return demb
 
 
-def walk_fwd(A, chain=CHAIN_F32, want_At=False):
-    """A [B,T-1,N,N] -> (loss 0-d, state buffer, At [B,T-2,N,N] or None)."""
+def walk_fwd(A, chain=CHAIN_F32, want_At=False, stats=None):
+    """A [B,T-1,N,N] (+ optional stats of affinity_fwd) -> (loss 0-d, state buffer, At [B,T-2,N,N] or None)."""
     B, Tm1, N, _ = A.shape
     T = Tm1 + 1
     nbytes = lib().crw_walk_state_bytes(B, T, N, chain)
     state = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
     loss = torch.empty((), dtype=torch.float32, device=A.device)
     At = torch.empty(B, max(T - 2, 0), N, N, device=A.device, dtype=torch.float32) if want_At else None
-    _check(lib().crw_walk_fwd(_dev(A, "A"), B, T, N, chain, ctypes.c_void_p(state.data_ptr()), nbytes,
+    if stats is not None and tuple(stats.shape) != (4, B, Tm1, N):
+        raise RuntimeError(f"stats must be [4, {B}, {Tm1}, {N}] (got {tuple(stats.shape)})")
+    _check(lib().crw_walk_fwd(_dev(A, "A"), _dev(stats, "stats") if stats is not None else None, B, T, N, chain,
+                              ctypes.c_void_p(state.data_ptr()), nbytes,
                               _dev(At, "At") if (want_At and T > 2) else None, _dev(loss, "loss"), _stream()),
            "crw_walk_fwd")
     return loss, state, At
 
 
-def walk_bwd(gloss, state, B, T, N, chain=CHAIN_F32):
+def walk_bwd(gloss, A, state, chain=CHAIN_F32):
+    """dLoss/dA for the logits A the forward ran on (the softmaxes are recomputed from A and the statistics in `state`)."""
+    B, Tm1, N, _ = A.shape
+    T = Tm1 + 1
     nbytes = lib().crw_walk_scratch_bytes(B, T, N, chain)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=state.device)
     dA = torch.empty(B, T - 1, N, N, device=state.device, dtype=torch.float32)
     g = gloss.reshape(1).to(torch.float32).contiguous()
-    _check(lib().crw_walk_bwd(_dev(g, "gloss"), B, T, N, chain, ctypes.c_void_p(state.data_ptr()), state.numel(),
+    _check(lib().crw_walk_bwd(_dev(g, "gloss"), _dev(A, "A"), B, T, N, chain, ctypes.c_void_p(state.data_ptr()), state.numel(),
                               ctypes.c_void_p(scratch.data_ptr()), nbytes, _dev(dA, "dA"), _stream()), "crw_walk_bwd")
     return dA
 

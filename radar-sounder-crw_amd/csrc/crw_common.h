@@ -106,13 +106,27 @@ struct EdgeGemm {
   int divide;               // 1: C = acc / scale, 0: C = acc * scale
 };
 int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s);
+// affinity build on 128 x 128 fp32-MFMA tiles with the softmax statistics in the epilogue (gemm_f32.hip):
+// A[b,t] = ehat[b,t] ehat[b,t+1]^T / tau, stats (optional) dense [4][B][T-1][N]; part: workspace of
+// affinity_part_floats(B, T, N) floats (per-tile partial statistics)
+size_t affinity_part_floats(int B, int T, int N);
+int launch_affinity_tiles(const float *ehat, int B, int T, int N, int C, float tau, float *A, float *stats, float *part,
+                          hipStream_t s);
+// dehat[b,t] = (dA[b,t] ehat[b,t+1] + dA[b,t-1]^T ehat[b,t-1]) / tau on fp32-MFMA tiles (C a multiple of 16, C <= 256)
+int launch_affinity_bwd_tiles(const float *dA, const float *ehat, int B, int T, int N, int C, float tau, float *dehat,
+                              hipStream_t s);
 
 // softmax.hip --------------------------------------------------------------------------------
-// A / dA are the caller's [B][T-1][N][N]; F, Gt, dF, dGt and the stats are internal [T-1][B][Np][Np]
-int launch_softmax_fwd(const float *A, int B, int Tm1, int N, int Np, float *F, float *Gt, void *Fb, void *Gtb,
-                       float *stats /* 4*B*Tm1*Np */, hipStream_t s);
-int launch_softmax_bwd(const float *F, const float *Gt, const float *dF, const float *dGt, int B, int Tm1, int N,
-                       int Np, float *stats /* 2*B*Tm1*Np */, float *dA, hipStream_t s);
+// A / dA are the caller's [B][T-1][N][N]; F, Gt, dF, dGt and the statistics are internal [T-1][B][Np][Np] / [..][Np].
+// stats_ext (optional): dense [4][B][T-1][N] row max / row sum / column max / column sum from crw_affinity_fwd.
+// Outputs of the forward pass are optional per family: fp32 planes (F, Gt) and / or bf16 images (Fh/Fl, Gh/Gl).
+int launch_softmax_fwd(const float *A, const float *stats_ext, int B, int Tm1, int N, int Np, float *F, float *Gt, void *Fh,
+                       void *Fl, void *Gh, void *Gl, float *stats /* 4*B*Tm1*Np */, hipStream_t s);
+// statistics of dense matrices in the caller's order: stats [4][nmat][N] (the layout crw_affinity_fwd hands out)
+int launch_stats_dense(const float *A, int nmat, int N, float *stats, hipStream_t s);
+// F / Gt are recomputed from A and the statistics; dots: 2*B*Tm1*Np floats of scratch
+int launch_softmax_bwd(const float *A, const float *stats, const float *dF, const float *dGt, int B, int Tm1, int N, int Np,
+                       float *dots, float *dA, hipStream_t s);
 // persistent small-n chain (chain_small.hip): X_{k+1} = P_k X_k  /  Y_k += P_k^T Y_{k+1}
 int launch_chain_small_fwd(const float *Gt, const float *F, float *Lt, float *R, int B, int K, int n, hipStream_t s);
 int launch_chain_small_bwd(const float *Gt, const float *F, float *dLt, float *dR, int B, int K, int n,
@@ -125,7 +139,7 @@ int launch_copy_f32(float *dst, const float *src, long dst_bs, long src_bs, long
 int launch_loss_rows(const float *At, int nmat, int N, int Np, float *lse, float *terms, hipStream_t s);
 int launch_loss_reduce(const float *terms, long n, float scale, float *loss, hipStream_t s);
 int launch_dAt(const float *At, const float *lse, const float *gloss, float coef, int nmat, int N, int Np,
-               float *dAt, void *dAtb, hipStream_t s);
+               float *dAt, void *dAt_hi, void *dAt_lo, hipStream_t s);
 int launch_unpad_At(const float *At, int K, int B, int N, int Np, float *out, hipStream_t s);
 
 }  // namespace crw

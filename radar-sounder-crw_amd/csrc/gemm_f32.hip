@@ -229,6 +229,209 @@ __global__ __launch_bounds__(256) void edge_gemm_kernel(EdgeGemm g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Affinity build and its backward on 128-row fp32-MFMA tiles (exact fp32 like the chain; the bounds-checked
+// edge_gemm_kernel above stays the fallback for channel counts that are not a multiple of 4 / node counts that are not).
+//
+// Bounds-aware operand stager (k-major LDS tile [BK][LD] like gemm_pad_f32_kernel): rows beyond `rmax` are clamped (their
+// products land in tile rows / columns that are masked at the store), k beyond `kmax` is zero-filled.  Loads are
+// unconditional at clamped addresses, then zeroed by a select (a predicated load makes hipcc wait for it on the spot).
+template <int R>
+struct BoundStager {
+  static constexpr int NV4 = R * BK / 4, PER = (NV4 + 255) / 256;
+  float4 v[PER];
+  // kcontig : X[(r0 + r) * ld + k0 + k]   (kmax % 4 == 0)         !kcontig: X[(k0 + k) * ld + r0 + r]   (rmax % 4 == 0)
+  __device__ inline void load(const float *__restrict__ X, long ld, int r0, int k0, bool kcontig, int rmax, int kmax, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = min(tid + i * 256, NV4 - 1);
+      if (kcontig) {
+        const int r = e >> 2, k = k0 + 4 * (e & 3);
+        const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(r0 + r, rmax - 1) * ld + min(k, kmax - 4));
+        v[i] = k < kmax ? t : float4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int k = k0 + e / (R / 4), r = r0 + 4 * (e % (R / 4));
+        const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(k, kmax - 1) * ld + min(r, rmax - 4));
+        v[i] = (k < kmax && r < rmax) ? t : float4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  template <int LD>
+  __device__ inline void store(float *S, bool kcontig, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + i * 256;
+      if (NV4 % 256 == 0 || e < NV4) {
+        if (kcontig) {
+          const int r = e >> 2, kq = e & 3;
+          S[(4 * kq + 0) * LD + r] = v[i].x;
+          S[(4 * kq + 1) * LD + r] = v[i].y;
+          S[(4 * kq + 2) * LD + r] = v[i].z;
+          S[(4 * kq + 3) * LD + r] = v[i].w;
+        } else {
+          const int k = e / (R / 4), rq = e % (R / 4);
+          *reinterpret_cast<float4 *>(S + k * LD + 4 * rq) = v[i];
+        }
+      }
+    }
+  }
+};
+
+// one 128 x 128 x BK MFMA block on k-major LDS tiles; wave (wm, wn) owns TM x TN 16 x 16 tiles
+template <int TM, int TN, int LDA, int LDB>
+__device__ inline void mfma_block(const float *As, const float *Bs, int wm, int wn, int lane, f32x4 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int kk = 0; kk < BK; kk += 4) {
+    float a[TM], bv[TN];
+    const int kr = kk + (lane >> 4), c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + wm + i * 16 + c];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = Bs[kr * LDB + wn + j * 16 + c];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+constexpr int AT = 128, ATLD = AT + 1;  // affinity tile and the row stride of its LDS image (conflict-free row AND column walks)
+
+// A[b,t] tile = ehat[b,t][m0..] ehat[b,t+1][n0..]^T / tau, plus (optional) the tile's partial softmax statistics:
+// per row the (max, sum exp) over the tile's valid columns -> rpart[mat][tn][row], per column over its rows -> cpart[mat][tm][col]
+__global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restrict__ ehat, int T, int N, int C, float tau,
+                                                            float *__restrict__ A, float *__restrict__ part, int tiles) {
+  constexpr int LD = AT + 16;
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float *As = lds_f, *Bs = lds_f + BK * LD, *tile = lds_f;  // the output tile reuses the operand space
+  const int tm = blockIdx.x / tiles, tn = blockIdx.x % tiles, m0 = tm * AT, n0 = tn * AT;
+  const long amat = blockIdx.y;                    // caller order: b * (T - 1) + t
+  const long b = amat / (T - 1), t = amat % (T - 1);
+  const float *E0 = ehat + (b * T + t) * (long)N * C, *E1 = E0 + (long)N * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  BoundStager<AT> sa, sb;
+  const int nk = (C + BK - 1) / BK;
+  sa.load(E0, C, m0, 0, true, N, C, tid);
+  sb.load(E1, C, n0, 0, true, N, C, tid);
+  for (int kt = 0; kt < nk; ++kt) {
+    sa.store<LD>(As, true, tid);
+    sb.store<LD>(Bs, true, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      sa.load(E0, C, m0, (kt + 1) * BK, true, N, C, tid);
+      sb.load(E1, C, n0, (kt + 1) * BK, true, N, C, tid);
+    }
+    mfma_block<4, 4, LD, LD>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+  // accumulators -> LDS image of the tile (already divided by tau)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        tile[(wm + 16 * i + 4 * (lane >> 4) + r) * ATLD + wn + 16 * j + (lane & 15)] = acc[i][j][r] / tau;
+  __syncthreads();
+  float *Ab = A + amat * (long)N * N;
+  for (int e = tid; e < AT * AT; e += 256) {  // a wave writes 64 consecutive columns of a row
+    const int r = e >> 7, c = e & 127;
+    if (m0 + r < N && n0 + c < N) Ab[(long)(m0 + r) * N + n0 + c] = tile[r * ATLD + c];
+  }
+  if (!part) return;
+  // threads 0..127: one tile row each; threads 128..255: one tile column each (both walks are bank-conflict free on ATLD)
+  const int idx = tid & 127;
+  const bool rows = tid < 128;
+  const int lim = rows ? min(AT, N - n0) : min(AT, N - m0);   // valid extent along the walk
+  const int step = rows ? 1 : ATLD;
+  const float *src = tile + (rows ? idx * ATLD : idx);
+  float m = -INFINITY;
+  for (int j = 0; j < lim; ++j) m = fmaxf(m, src[j * step]);
+  float sum = 0.f;
+  for (int j = 0; j < lim; ++j) sum += expf(src[j * step] - m);
+  const int gi = (rows ? m0 : n0) + idx;
+  if (gi < N) {
+    // part: [2 (row / column)][nmat][tiles][N][2]
+    const long nmat = gridDim.y;
+    float *dst = part + ((((rows ? 0 : nmat) + amat) * tiles + (rows ? tn : tm)) * (long)N + gi) * 2;
+    dst[0] = m;
+    dst[1] = sum;
+  }
+}
+
+// merge the per-tile partials in tile order (deterministic): stats dense [4][nmat][N]
+__global__ __launch_bounds__(256) void affinity_stats_merge_kernel(const float *__restrict__ part, int nmat, int tiles, int N,
+                                                                   float *__restrict__ stats) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over 2 * nmat * N
+  if (i >= 2L * nmat * N) return;
+  const long which = i / ((long)nmat * N), rem = i % ((long)nmat * N), mat = rem / N, n = rem % N;
+  const float *p = part + ((which * nmat + mat) * tiles * (long)N + n) * 2;
+  float m = -INFINITY;
+  for (int t = 0; t < tiles; ++t) m = fmaxf(m, p[(long)t * N * 2]);
+  float s = 0.f;
+  for (int t = 0; t < tiles; ++t) s += p[(long)t * N * 2 + 1] * expf(p[(long)t * N * 2] - m);
+  stats[((2 * which) * nmat + mat) * N + n] = m;
+  stats[((2 * which + 1) * nmat + mat) * N + n] = s;
+}
+
+// dehat[b,t] tile (128 rows x C) = (dA[b,t] ehat[b,t+1] + dA[b,t-1]^T ehat[b,t-1]) / tau;  N % 4 == 0, C = 32 * TN2 * 2
+template <int TN>  // 16-wide column tiles per wave: C = 32 * TN
+__global__ __launch_bounds__(256) void affinity_bwd_tile_kernel(const float *__restrict__ dA, const float *__restrict__ ehat,
+                                                                int T, int N, float tau, float *__restrict__ dehat) {
+  constexpr int C = 32 * TN, LDA = AT + 16, LDB = C + 16;
+  __shared__ __attribute__((aligned(16))) float lds_f[BK * LDA + BK * LDB];
+  float *As = lds_f, *Bs = lds_f + BK * LDA;
+  const int m0 = blockIdx.x * AT;
+  const long bt = blockIdx.y, b = bt / T, t = bt % T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (C / 2);
+  f32x4 acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  BoundStager<AT> sa;
+  BoundStager<C> sb;
+  const long NN = (long)N * N, NC = (long)N * C;
+  const int nk = (N + BK - 1) / BK;
+  for (int prod = 0; prod < 2; ++prod) {
+    if (prod == 0 ? t == T - 1 : t == 0) continue;  // block-uniform
+    // product 0: dA[b,t] (row n, k = m), k-contiguous; product 1: dA[b,t-1]^T (row n, k = m) = dA[b,t-1][m][n], r-contiguous
+    const float *X = dA + (b * (T - 1) + (prod == 0 ? t : t - 1)) * NN;
+    const float *E = ehat + (b * T + (prod == 0 ? t + 1 : t - 1)) * NC;
+    const bool akc = prod == 0;
+    sa.load(X, N, m0, 0, akc, N, N, tid);
+    sb.load(E, C, 0, 0, false, C, N, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+      sa.template store<LDA>(As, akc, tid);
+      sb.template store<LDB>(Bs, false, tid);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        sa.load(X, N, m0, (kt + 1) * BK, akc, N, N, tid);
+        sb.load(E, C, 0, (kt + 1) * BK, false, C, N, tid);
+      }
+      mfma_block<4, TN, LDA, LDB>(As, Bs, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  }
+  float *D = dehat + bt * NC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+        if (row < N) D[(long)row * C + wn + 16 * j + (lane & 15)] = acc[i][j][r] / tau;
+      }
+}
+
 // largest tile (128 / 64 / 32) that divides n and still yields a well-filled grid
 int pick_tile(int n, long batch_times_prob) {
   const int cand[3] = {128, 64, 32};
@@ -260,6 +463,46 @@ int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s) {
   if (g.M < 1 || g.N < 1 || batch < 1) return CRW_EINVAL;
   dim3 grid((g.N + EB - 1) / EB, (g.M + EB - 1) / EB, batch);
   hipLaunchKernelGGL(edge_gemm_kernel, grid, dim3(256), 0, s, g);
+  return check_launch();
+}
+
+size_t affinity_part_floats(int B, int T, int N) {
+  const size_t tiles = (N + AT - 1) / AT;
+  return (size_t)2 * B * (T - 1) * tiles * N * 2;
+}
+
+int launch_affinity_tiles(const float *ehat, int B, int T, int N, int C, float tau, float *A, float *stats, float *part,
+                          hipStream_t s) {
+  if (C % 4 || C < 4 || (stats && !part)) return CRW_EINVAL;
+  const int tiles = (N + AT - 1) / AT, nmat = B * (T - 1);
+  const size_t lds = sizeof(float) * (size_t)(AT * ATLD > 2 * BK * (AT + 16) ? AT * ATLD : 2 * BK * (AT + 16));
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void *)affinity_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(affinity_tile_kernel, dim3(tiles * tiles, nmat), dim3(256), lds, s, ehat, T, N, C, tau, A,
+                     stats ? part : nullptr, tiles);
+  if (stats) {
+    const long n = 2L * nmat * N;
+    hipLaunchKernelGGL(affinity_stats_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nmat, tiles, N, stats);
+  }
+  return check_launch();
+}
+
+int launch_affinity_bwd_tiles(const float *dA, const float *ehat, int B, int T, int N, int C, float tau, float *dehat,
+                              hipStream_t s) {
+  if (N % 4 || N < 4) return CRW_EINVAL;
+  const dim3 grid((N + AT - 1) / AT, B * T);
+  switch (C) {
+    case 32: hipLaunchKernelGGL(affinity_bwd_tile_kernel<1>, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat); break;
+    case 64: hipLaunchKernelGGL(affinity_bwd_tile_kernel<2>, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat); break;
+    case 128: hipLaunchKernelGGL(affinity_bwd_tile_kernel<4>, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat); break;
+    default: return CRW_EINVAL;
+  }
   return check_launch();
 }
 

@@ -99,8 +99,8 @@ WalkState layout_state(void *base, int B, int T, int N, int chain) {
   const size_t Np = chain_padded_nodes(N, chain), K = T - 2, nA = (size_t)B * (T - 1), M = Np * Np;
   char *p = static_cast<char *>(base);
   WalkState s;
-  s.F = carve_mat(p, nA * M, chain, true);    // fp32 kept for the softmax backward
-  s.Gt = carve_mat(p, nA * M, chain, true);
+  s.F = carve_mat(p, nA * M, chain, false);   // bf16 chains: images only (the softmax backward recomputes F / Gt from A)
+  s.Gt = carve_mat(p, nA * M, chain, false);
   s.Lt = carve_mat(p, K * B * M, chain, false);  // bf16 chains: operands only
   s.R = carve_mat(p, K * B * M, chain, false);
   s.At = carve_mat(p, K * B * M, chain, true, false);  // loss needs fp32; never a GEMM operand
@@ -115,7 +115,7 @@ WalkScratch layout_scratch(void *base, int B, int T, int N, int chain) {
   const size_t Np = chain_padded_nodes(N, chain), K = T - 2, nA = (size_t)B * (T - 1), M = Np * Np;
   char *p = static_cast<char *>(base);
   WalkScratch s;
-  s.dAt = carve_mat(p, K * B * M, chain, true);
+  s.dAt = carve_mat(p, K * B * M, chain, false);  // bf16 chains: only ever a GEMM operand
   s.dF = carve_mat(p, nA * M, chain, true, false);
   s.dGt = carve_mat(p, nA * M, chain, true, false);
   s.dLt = carve_mat(p, K * B * M, chain, true);  // fp32 needed: accumulated in place (beta = 1)
@@ -125,7 +125,8 @@ WalkScratch layout_scratch(void *base, int B, int T, int N, int chain) {
   return s;
 }
 
-bool bad_shape(int B, int T, int N) { return B < 1 || T < 2 || N < 1 || N > 16384; }
+// (matrix counts ride in grid.y / grid.z of the elementwise and edge launches: B * T <= 65535)
+bool bad_shape(int B, int T, int N) { return B < 1 || T < 2 || N < 1 || N > 16384 || (long)B * T > 65535; }
 bool bad_chain(int chain) { return chain != CRW_CHAIN_F32 && chain != CRW_CHAIN_BF16 && chain != CRW_CHAIN_BF16X3; }
 
 // operand / result descriptors for either arithmetic
@@ -185,11 +186,6 @@ int launch_group(const GemmGroup &g, int chain, hipStream_t s) {
   }
   return CRW_OK;
 }
-// fp32 plane -> bf16 images of the same family (no-op for the fp32 chain)
-int make_images(const Mat &m, long count, hipStream_t s) {
-  if (!m.h) return CRW_OK;
-  return launch_split_bf16(m.f, count, m.h, m.l, s);
-}
 
 }  // namespace
 }  // namespace crw
@@ -198,7 +194,7 @@ using namespace crw;
 
 extern "C" {
 
-int crw_abi_version(void) { return 2; }
+int crw_abi_version(void) { return 3; }
 const char *crw_build_arch(void) { return "gfx950"; }
 int crw_last_hip_error(void) { return g_last_hip_error; }
 int crw_padded_nodes(int N, int chain) { return (N < 1 || bad_chain(chain)) ? 0 : chain_padded_nodes(N, chain); }
@@ -220,12 +216,20 @@ int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, c
   return check_launch();
 }
 
+size_t crw_affinity_ws_bytes(int B, int T, int N) {
+  if (bad_shape(B, T, N)) return 0;
+  return affinity_part_floats(B, T, N) * sizeof(float);
+}
+
 int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau, float *ehat, float *norm, float *A,
-                     crw_stream_t stream) {
+                     float *stats, void *ws, size_t ws_bytes, crw_stream_t stream) {
   crw::clear_stale_error();
   if (!emb || !ehat || !norm || !A || bad_shape(B, T, N) || C < 1 || !(tau > 0.f)) return CRW_EINVAL;
+  if (stats && (!ws || ws_bytes < crw_affinity_ws_bytes(B, T, N))) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   CRW_TRY(crw_normalize(emb, B * T * N, C, ehat, norm, stream));
+  if (C % 4 == 0)  // 128 x 128 fp32-MFMA tiles, statistics in the epilogue
+    return launch_affinity_tiles(ehat, B, T, N, C, tau, A, stats, static_cast<float *>(ws), s);
   EdgeGemm g{};
   const long NC = (long)N * C, NN = (long)N * N;
   g.A = EdgeOperand{ehat, NC, C, 1};            // (n, c) of frame j
@@ -238,11 +242,13 @@ int crw_affinity_fwd(const float *emb, int B, int T, int N, int C, float tau, fl
   g.sC_outer = (long)(T - 1) * NN;
   g.skip1_inner = g.skip2_inner = -1;
   g.scale = tau; g.divide = 1;
-  return launch_edge_gemm(g, B * (T - 1), s);
+  CRW_TRY(launch_edge_gemm(g, B * (T - 1), s));
+  if (stats) CRW_TRY(launch_stats_dense(A, B * (T - 1), N, stats, s));  // odd channel counts: one extra pass over A
+  return CRW_OK;
 }
 
-int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, size_t state_bytes, float *At_out,
-                 float *loss, crw_stream_t stream) {
+int crw_walk_fwd(const float *A, const float *stats_ext, int B, int T, int N, int chain, void *state, size_t state_bytes,
+                 float *At_out, float *loss, crw_stream_t stream) {
   crw::clear_stale_error();
   if (!A || !loss || bad_shape(B, T, N) || bad_chain(chain)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -257,9 +263,8 @@ int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, si
   const long M = (long)Np * Np, BM = (long)B * M;  // every family is [k][b][Np][Np]: k stride BM, batch stride M
   const bool small = chain == CRW_CHAIN_F32 && Np <= 64;
 
-  CRW_TRY(launch_softmax_fwd(A, B, T - 1, N, Np, st.F.f, st.Gt.f, nullptr, nullptr, st.stats, s));
-  CRW_TRY(make_images(st.F, (long)nA * M, s));
-  CRW_TRY(make_images(st.Gt, (long)nA * M, s));
+  (void)nA;
+  CRW_TRY(launch_softmax_fwd(A, stats_ext, B, T - 1, N, Np, st.F.f, st.Gt.f, st.F.h, st.F.l, st.Gt.h, st.Gt.l, st.stats, s));
   if (chain == CRW_CHAIN_F32) {
     CRW_TRY(launch_identity(st.R.f, nullptr, B, Np, N, s, st.Lt.f, st.Gt.f));  // R_1 = I and Lt_1 = Gt_0
   } else {  // the same on the bf16 images (two bf16 per float lane of the copy kernel)
@@ -302,10 +307,10 @@ int crw_walk_fwd(const float *A, int B, int T, int N, int chain, void *state, si
   return CRW_OK;
 }
 
-int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state, size_t state_bytes, void *scratch,
-                 size_t scratch_bytes, float *dA, crw_stream_t stream) {
+int crw_walk_bwd(const float *gloss, const float *A, int B, int T, int N, int chain, void *state, size_t state_bytes,
+                 void *scratch, size_t scratch_bytes, float *dA, crw_stream_t stream) {
   crw::clear_stale_error();
-  if (!gloss || !dA || bad_shape(B, T, N) || bad_chain(chain)) return CRW_EINVAL;
+  if (!gloss || !A || !dA || bad_shape(B, T, N) || bad_chain(chain)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long NN = (long)N * N;
   if (T < 3) {
@@ -321,8 +326,7 @@ int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state
   const bool small = chain == CRW_CHAIN_F32 && Np <= 64;
 
   const float coef = 1.0f / ((float)N * (float)B * (float)N);
-  CRW_TRY(launch_dAt(st.At.f, st.lse, gloss, coef, K * B, N, Np, sc.dAt.f, nullptr, s));
-  CRW_TRY(make_images(sc.dAt, K * BM, s));
+  CRW_TRY(launch_dAt(st.At.f, st.lse, gloss, coef, K * B, N, Np, sc.dAt.f, sc.dAt.h, sc.dAt.l, s));
   // slices no product writes: dF_0, dF_{T-2}, dGt_{T-2}
   if ((reinterpret_cast<uintptr_t>(sc.dF.f) | reinterpret_cast<uintptr_t>(sc.dGt.f)) & 15) {  // caller's scratch not 16-byte aligned
     if (hipMemsetAsync(sc.dF.f, 0, sizeof(float) * BM, s) != hipSuccess) return CRW_EHIP;
@@ -384,7 +388,7 @@ int crw_walk_bwd(const float *gloss, int B, int T, int N, int chain, void *state
   }
   // Lt_1 = Gt_0  ->  dGt_0 = dLt_1
   CRW_TRY(launch_copy_f32(sc.dGt.f, sc.dLt.f, 0, 0, BM, 1, s));
-  CRW_TRY(launch_softmax_bwd(st.F.f, st.Gt.f, sc.dF.f, sc.dGt.f, B, T - 1, N, Np, sc.stats, dA, s));
+  CRW_TRY(launch_softmax_bwd(A, st.stats, sc.dF.f, sc.dGt.f, B, T - 1, N, Np, sc.stats, dA, s));
   return CRW_OK;
 }
 
@@ -394,6 +398,12 @@ int crw_affinity_bwd(const float *dA, const float *ehat, const float *norm, int 
   if (!dA || !ehat || !norm || !dehat_ws || !demb || bad_shape(B, T, N) || C < 1 || !(tau > 0.f)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long NC = (long)N * C, NN = (long)N * N;
+  if (N % 4 == 0 && (C == 32 || C == 64 || C == 128)) {  // 128-row fp32-MFMA tiles
+    CRW_TRY(launch_affinity_bwd_tiles(dA, ehat, B, T, N, C, tau, dehat_ws, s));
+    const long rows_ = (long)B * T * N;
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)((rows_ + 3) / 4)), dim3(256), 0, s, dehat_ws, ehat, norm, rows_, C, demb);
+    return check_launch();
+  }
   EdgeGemm g{};
   // product 1 (frames t < T-1): dA[b,t] (n, m) x ehat[b,t+1] (m, c)
   g.A = EdgeOperand{dA, NN, N, 1};

@@ -11,6 +11,8 @@ results, the default; "bf16" = plain bf16 operands; None = PyTorch-ROCm ops).  O
 head stays a PyTorch op.  At other patch sizes, inference (``torch.no_grad``) runs conv3-5 + pooling on the tiled
 HIP kernels (``_hip_inference_trunk``) and training uses PyTorch ops; CPU tensors and ``Resnet`` use PyTorch ops.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
@@ -96,6 +98,7 @@ def _report(module):
 class CNN(nn.Module):
     """Five conv layers (5x5, 5x5, 3x3, 3x3, 3x3; all padding 1) with ReLU, stride-1 max-pools
     after the first two, global average pool and a linear head -> 128-d feature per patch."""
+    _warned_fallback = False  # the PyTorch-op path on a GPU warns once per process
 
     def __init__(self, pos_embed):
         super().__init__()
@@ -121,6 +124,12 @@ class CNN(nn.Module):
         if (self.hip_convs and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
                 and min(x.shape[-2:]) >= 7):
             return self._head(self._hip_inference_trunk(x))
+        if self.hip_convs and x.is_cuda and not CNN._warned_fallback:
+            # not silent: the caller believes it is on the hand-written kernels (set hip_convs = None to choose this path)
+            CNN._warned_fallback = True
+            warnings.warn(f"CNN.forward: input {tuple(x.shape)} {x.dtype} (grad enabled: {torch.is_grad_enabled()}) is not covered by "
+                          "the HIP conv kernels (float32 patches; training needs 16x16 patches, inference >= 7x7): this call "
+                          "runs on PyTorch-ROCm / MIOpen convolutions", RuntimeWarning, stacklevel=2)
         for name, _, _, pooled in _CNN_STACK:
             x = getattr(self, "relu" + name)(getattr(self, "conv" + name)(x))
             if pooled:

@@ -18,43 +18,53 @@ from utils import pos_embed
 
 
 class _Affinity(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, emb, tau):
-        A, ehat, norm = crw_hip.affinity_fwd(emb.contiguous().float(), tau)
-        ctx.save_for_backward(ehat, norm)
-        ctx.tau = tau
-        return A
+    """-> (A, stats): the logits and, from the same kernel's epilogue, the statistics of their two softmaxes (not differentiable:
+    they only save `walk_loss` a pass over A)."""
 
     @staticmethod
-    def backward(ctx, dA):
+    def forward(ctx, emb, tau):
+        A, ehat, norm, stats = crw_hip.affinity_fwd(emb.contiguous().float(), tau)
+        ctx.save_for_backward(ehat, norm)
+        ctx.tau = tau
+        if stats is None:
+            return A, None
+        ctx.mark_non_differentiable(stats)
+        return A, stats
+
+    @staticmethod
+    def backward(ctx, dA, _dstats=None):
         ehat, norm = ctx.saved_tensors
         return crw_hip.affinity_bwd(dA.contiguous(), ehat, norm, ctx.tau), None
 
 
 class _WalkLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, A, chain):
-        B, Tm1, N, _ = A.shape
-        loss, state, _ = crw_hip.walk_fwd(A.contiguous(), chain)
-        ctx.save_for_backward(state)  # freed by autograd after backward (kept under retain_graph)
-        ctx.dims, ctx.chain = (B, Tm1 + 1, N), chain
+    def forward(ctx, A, chain, stats):
+        A = A.contiguous()
+        loss, state, _ = crw_hip.walk_fwd(A, chain, stats=stats)
+        ctx.save_for_backward(A, state)  # freed by autograd after backward (kept under retain_graph)
+        ctx.chain = chain
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        B, T, N = ctx.dims
-        (state,) = ctx.saved_tensors
-        return crw_hip.walk_bwd(gloss, state, B, T, N, ctx.chain), None
+        A, state = ctx.saved_tensors
+        return crw_hip.walk_bwd(gloss, A, state, ctx.chain), None, None
 
 
 def affinity(emb, tau):
     """emb [B,T,N,C] (raw encoder output) -> logits A [B,T-1,N,N]; differentiable."""
+    return _Affinity.apply(emb, float(tau))[0]
+
+
+def affinity_with_stats(emb, tau):
+    """-> (A, stats [4,B,T-1,N]): pass both to `walk_loss` and the walk skips its statistics pass over A."""
     return _Affinity.apply(emb, float(tau))
 
 
-def walk_loss(A, chain=crw_hip.CHAIN_F32):
+def walk_loss(A, chain=crw_hip.CHAIN_F32, stats=None):
     """A [B,T-1,N,N] -> cycle-consistency loss (0-d); differentiable."""
-    return _WalkLoss.apply(A, chain)
+    return _WalkLoss.apply(A, chain, stats)
 
 
 class CRW(nn.Module):
@@ -72,10 +82,10 @@ class CRW(nn.Module):
         if self.pos_embed:
             x = pos_embed(x)
         emb = self.encoder(x).reshape(B, T, N, -1)
-        A = affinity(emb, self.tau)
+        A, stats = affinity_with_stats(emb, self.tau)
         if self.only_a:
             return A
-        return walk_loss(A, self.chain), A
+        return walk_loss(A, self.chain, stats), A
 
     def forward_columns(self, cols, length, stride=1):
         """Shared-encoder training step over OVERLAPPING items (opt-in, not in

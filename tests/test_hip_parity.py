@@ -135,6 +135,38 @@ def test_bf16_chain_modes_on_256_tiles_match_oracle(hip, chain):
     np.testing.assert_allclose(emb.grad.cpu().numpy(), o["demb"], rtol=10 * tol, atol=tol * scale)
 
 
+@pytest.mark.parametrize("B,T,N,C,tau", [(2, 4, 63, 128, 0.01), (1, 3, 130, 64, 0.05), (2, 3, 257, 32, 0.1), (1, 5, 512, 128, 0.02),
+                                         (1, 3, 40, 20, 0.07)])
+def test_affinity_tiles_and_fused_statistics(hip, B, T, N, C, tau):
+    """crw_affinity_fwd on the fp32-MFMA tiles: logits against fp64, the softmax statistics of its epilogue (per-tile partials
+    merged in tile order) against a direct computation, and the walk fed with them against the walk that computes its own
+    (both softmax paths: imported statistics / stats kernel).  Also the tiled affinity backward (N % 4 == 0, C in {32, 64,
+    128}) and the bounds-checked fallback against fp64."""
+    g = torch.Generator().manual_seed(N + C)
+    emb = (torch.randn(1, 1, N, C, generator=g) + 0.6 * torch.randn(B, T, N, C, generator=g)).float()
+    A, ehat, norm, stats = hip.affinity_fwd(emb.cuda(), tau)
+    eh = emb.double() / emb.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    A_ref = torch.einsum("btnc,btmc->btnm", eh[:, :-1], eh[:, 1:]) / tau
+    torch.testing.assert_close(A.cpu().double(), A_ref, rtol=1e-5, atol=2e-5 / tau * 1e-1)
+    Ad = A.double()
+    rmax, cmax = Ad.max(-1).values, Ad.max(-2).values
+    rsum, csum = (Ad - rmax[..., None]).exp().sum(-1), (Ad - cmax[..., None, :]).exp().sum(-2)
+    for got, want in zip(stats, (rmax, rsum, cmax, csum)):
+        torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-6)
+    l0, _, At0 = hip.walk_fwd(A, want_At=True)
+    l1, _, At1 = hip.walk_fwd(A, want_At=True, stats=stats)
+    assert abs(l0.item() - l1.item()) <= 1e-6 * max(1.0, abs(l0.item()))
+    torch.testing.assert_close(At0, At1, rtol=1e-5, atol=1e-7)
+    dA = torch.randn(B, T - 1, N, N, generator=g).float()
+    demb = hip.affinity_bwd(dA.cuda(), ehat, norm, tau)
+    deh = torch.zeros_like(eh)
+    deh[:, :-1] += torch.einsum("btnm,btmc->btnc", dA.double(), eh[:, 1:]) / tau
+    deh[:, 1:] += torch.einsum("btnm,btnc->btmc", dA.double(), eh[:, :-1]) / tau
+    nrm = emb.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    want = (deh - eh * (eh * deh).sum(-1, keepdim=True)) / nrm
+    torch.testing.assert_close(demb.cpu().double(), want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
+
+
 def test_no_cycle_T2(hip):
     import model as crw_model
     g = load_golden("walk_T2_nocycle")
@@ -173,7 +205,7 @@ def test_walk_backward_dA_matches_oracle(hip):
     dA_ref = orc.walk_backward(A_cpu.double().numpy(), gloss=0.7)
     A = A_cpu.cuda()
     loss, state, _ = hip.walk_fwd(A)
-    dA = hip.walk_bwd(torch.tensor(0.7).cuda(), state, 2, 7, 40)
+    dA = hip.walk_bwd(torch.tensor(0.7).cuda(), A, state)
     np.testing.assert_allclose(dA.cpu().numpy(), dA_ref, rtol=1e-3, atol=1e-4 * np.abs(dA_ref).max())
     # A_{T-2} never enters the loss
     assert torch.count_nonzero(dA[:, -1]).item() == 0
