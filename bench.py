@@ -94,7 +94,7 @@ def walk_probe(B, T, N, iters=20):
 
     def step():
         emb = emb0.clone().requires_grad_(True)
-        crw_model.walk_loss(crw_model.affinity(emb, TAU)).backward()
+        crw_model.walk_loss(*crw_model.affinity_with_stats(emb, TAU)).backward()
 
     for _ in range(3):
         step()
@@ -190,8 +190,8 @@ def bench_chain(args):
 
         def step():
             emb = emb0.clone().requires_grad_(True)
-            A = crw_model.affinity(emb, 0.05)
-            loss = crw_model.walk_loss(A, chain)
+            A, stats = crw_model.affinity_with_stats(emb, 0.05)  # what CRW.forward does
+            loss = crw_model.walk_loss(A, chain, stats)
             loss.backward()
             return loss
 

@@ -62,8 +62,13 @@ def affinity_with_stats(emb, tau):
     return _Affinity.apply(emb, float(tau))
 
 
-def walk_loss(A, chain=crw_hip.CHAIN_F32, stats=None):
-    """A [B,T-1,N,N] -> cycle-consistency loss (0-d); differentiable."""
+def walk_loss(A, stats_or_chain=None, stats=None, chain=None):
+    """A [B,T-1,N,N] -> cycle-consistency loss (0-d); differentiable.  Accepts walk_loss(A), walk_loss(A, chain),
+    walk_loss(A, chain, stats) and walk_loss(*affinity_with_stats(emb, tau)) (= walk_loss(A, stats))."""
+    if torch.is_tensor(stats_or_chain):
+        stats, stats_or_chain = stats_or_chain, None
+    if chain is None:
+        chain = crw_hip.CHAIN_F32 if stats_or_chain is None else stats_or_chain
     return _WalkLoss.apply(A, chain, stats)
 
 
