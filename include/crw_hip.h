@@ -148,15 +148,25 @@ int crw_enc_conv3x3(int mode, int split, int P, int cin, int cout, const uint16_
                     const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi,
                     uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap, const float *dgap,
                     crw_stream_t stream);
-/* Forward conv + bias + ReLU on feature maps of ANY size (patch sizes other than 16x16; src/encoder.py:49-53 is
- * size-agnostic): planes are [P][H][W][C]; a workgroup computes one 10x10 output tile.  y_hi/y_lo may be NULL
- * when only the pooled result is wanted; gap_part [P * ceil(H/10) * ceil(W/10)][cout] receives per-tile SUMS
- * over the in-map pixels (the caller adds the tiles and divides by H*W = AdaptiveAvgPool2d(1)). */
-int crw_enc_conv3x3_map(int split, int P, int H, int W, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
-                        const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, uint16_t *y_hi, uint16_t *y_lo,
-                        float *gap_part, crw_stream_t stream);
-/* dY planes [P][100][C] = dgap[P][C] / 100 where y_hi != 0 (backward of ReLU + global average pool) */
-int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
+/* The 3x3 layers on feature maps of ANY size (patch sizes other than 16x16; src/encoder.py:49-53 is size-agnostic):
+ * planes are [P][H][W][C]; a workgroup computes one 10x10 output tile from the 12x12 window around it (zeros outside
+ * the map).  mode 0: relu(conv + bias); y_hi/y_lo may be NULL when only the pooled result is wanted; gap_part
+ * [P * ceil(H/10) * ceil(W/10)][cout] receives per-tile SUMS over the in-map pixels (the caller adds the tiles and
+ * divides by H*W = AdaptiveAvgPool2d(1)).  mode 1: backward-data (w = the backward planes of crw_enc_pack_weights,
+ * cin/cout swapped), output zeroed where mask_hi (activation map of the layer below, may be NULL) is 0; y_f32
+ * (may be NULL): fp32 copy of the output [P][H][W][cout]. */
+int crw_enc_conv3x3_map(int mode, int split, int P, int H, int W, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
+                        const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi,
+                        uint16_t *y_hi, uint16_t *y_lo, float *y_f32, float *gap_part, crw_stream_t stream);
+/* weight / bias gradient of one 3x3 layer on feature maps of any size (autograd of src/encoder.py:49-53 at other patch
+ * sizes): dY [P][H][W][cout], X [P][H][W][cin] planes -> dw [cout][cin][3][3], db [cout].
+ * ws: crw_enc_wgrad_ws_bytes(P * ceil(H/10) * ceil(W/10), cin, cout, split). */
+int crw_enc_conv3x3_wgrad_map(int split, int P, int H, int W, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
+                              const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, void *ws, size_t ws_bytes,
+                              crw_stream_t stream);
+/* dY planes [P][npix][C] = dgap[P][C] / npix where y_hi != 0 (backward of ReLU + global average pool; npix = 100 for
+ * 16x16 patches, H*W of the conv3-5 feature map otherwise) */
+int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, int npix, uint16_t *dy_hi, uint16_t *dy_lo,
                     crw_stream_t stream);
 /* dw [cout][cin][3][3], db [cout] (fp32, overwritten) from dY planes [P][100][cout] and x planes [P][100][cin].
  * Per-slice partial sums go to `ws` (crw_enc_wgrad_ws_bytes) and are added in a fixed order:

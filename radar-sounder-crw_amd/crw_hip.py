@@ -42,9 +42,10 @@ SIGNATURES = {
     "crw_enc_pack_weights": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "crw_enc_pack_input_map": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "crw_enc_conv3x3_map": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_conv3x3_map": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_conv3x3_wgrad_map": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_enc_conv3x3": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p]),
+    "crw_enc_gap_bwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_enc_wgrad_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_enc_front_pack": (_c_int, [_p, _p, _p, _p, _p, _p]),
@@ -307,26 +308,53 @@ def enc_pack_input_map(x, split):
     return xh, xl
 
 
-def enc_conv3x3_map(split, xh, xl, wh, wl, cout, H, W, bias=None, planes=True, gap=False, lo_plane=True):
-    """relu(conv3x3 + bias) on feature maps [P, H*W, cin] of any size -> (yh, yl, gap [P, cout] mean | None)."""
+def enc_conv3x3_map(split, xh, xl, wh, wl, cout, H, W, bias=None, planes=True, gap=False, lo_plane=True, mode=0, mask=None,
+                    f32=False):
+    """mode 0: relu(conv3x3 + bias) on feature maps [P, H*W, cin] of any size -> (yh, yl, gap [P, cout] mean | None);
+    mode 1: backward-data with the backward weight planes, optional ReLU mask map and fp32 copy -> (yh, yl, yf)."""
     P, hw, cin = xh.shape
     assert hw == H * W
     dev = xh.device
     yh = torch.empty(P, hw, cout, dtype=_BF, device=dev) if planes else None
     yl = torch.empty_like(yh) if (planes and split == 3 and lo_plane) else None
+    yf = torch.empty(P, hw, cout, dtype=torch.float32, device=dev) if f32 else None
     ntile = ((H + 9) // 10) * ((W + 9) // 10)
     gp = torch.empty(P, ntile, cout, dtype=torch.float32, device=dev) if gap else None
-    _check(lib().crw_enc_conv3x3_map(split, P, H, W, cin, cout, _bf(xh, "xh"), _bf(xl, "xl"), _bf(wh, "wh"), _bf(wl, "wl"),
-                                     _dev(bias, "bias") if bias is not None else None, _bf(yh, "yh"), _bf(yl, "yl"),
-                                     _dev(gp, "gap") if gap else None, _stream()), "crw_enc_conv3x3_map")
+    ev = _ev_begin()
+    _check(lib().crw_enc_conv3x3_map(mode, split, P, H, W, cin, cout, _bf(xh, "xh"), _bf(xl, "xl"), _bf(wh, "wh"), _bf(wl, "wl"),
+                                     _dev(bias, "bias") if bias is not None else None, _bf(mask, "mask"), _bf(yh, "yh"),
+                                     _bf(yl, "yl"), _dev(yf, "yf") if f32 else None, _dev(gp, "gap") if gap else None, _stream()),
+           "crw_enc_conv3x3_map")
+    _ev_end(ev, ("fwd_map", cin, cout) if mode == 0 else ("bwd_map", cout, cin))
+    if mode == 1:
+        return yh, yl, yf
     return yh, yl, (gp.sum(1) / float(hw) if gap else None)
 
 
+def enc_wgrad_map(split, dyh, dyl, xh, xl, H, W):
+    """weight / bias gradient of a 3x3 layer on feature maps [P, H*W, C] -> (dw [cout,cin,3,3], db [cout])."""
+    P, hw, cout = dyh.shape
+    cin = xh.shape[2]
+    assert hw == H * W
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=xh.device)
+    db = torch.empty(cout, dtype=torch.float32, device=xh.device)
+    units = P * ((H + 9) // 10) * ((W + 9) // 10)
+    nbytes = lib().crw_enc_wgrad_ws_bytes(units, cin, cout, split)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xh.device)
+    ev = _ev_begin()
+    _check(lib().crw_enc_conv3x3_wgrad_map(split, P, H, W, cin, cout, _bf(dyh, "dyh"), _bf(dyl, "dyl"), _bf(xh, "xh"),
+                                           _bf(xl, "xl"), _dev(dw, "dw"), _dev(db, "db"), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                           _stream()), "crw_enc_conv3x3_wgrad_map")
+    _ev_end(ev, ("wgrad_map", cin, cout))
+    return dw, db
+
+
 def enc_gap_bwd(dgap, yh, split):
-    P, _, C = yh.shape
+    """dY = dgap / npix where yh != 0, for planes [P, npix, C] of any map size."""
+    P, npix, C = yh.shape
     dh = torch.empty_like(yh)
     dl = torch.empty_like(yh) if split == 3 else None
-    _check(lib().crw_enc_gap_bwd(_dev(dgap.contiguous(), "dgap"), _bf(yh, "yh"), P, C, _bf(dh, "dh"), _bf(dl, "dl"),
+    _check(lib().crw_enc_gap_bwd(_dev(dgap.contiguous(), "dgap"), _bf(yh, "yh"), P, C, npix, _bf(dh, "dh"), _bf(dl, "dl"),
                                  _stream()), "crw_enc_gap_bwd")
     return dh, dl
 

@@ -456,7 +456,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
               v = fmaxf(v + bias_r[j], 0.f);
               if (!MAP || (ty0 + i / IMG_W < a.mh && tx0 + i % IMG_W < a.mw)) gsum[j] += v;
             }
-            if (!MAP && a.yf) a.yf[((long)p * NPIX + i) * COUT + co] = v;
+            if (a.yf) {
+              if constexpr (MAP) {
+                const int oy = ty0 + i / IMG_W, ox = tx0 + i % IMG_W;
+                if (oy < a.mh && ox < a.mw) a.yf[(((long)p * a.mh + oy) * a.mw + ox) * COUT + co] = v;
+              } else {
+                a.yf[((long)p * NPIX + i) * COUT + co] = v;
+              }
+            }
             if (a.yh) {
               const uint16_t h = f2bf(v);
               *reinterpret_cast<uint16_t *>(img + pp * RSO + 2 * co) = h;
@@ -484,13 +491,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
     // applied here, 8 channels at a time, from the matching chunk of its activation plane
     constexpr int NCH = COUT / 8, TOTAL = NPIX * NCH, ITER = (TOTAL + NT - 1) / NT;
     const int p = p0;
-    const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (long)p * NPIX * COUT : nullptr;
+    const uint16_t *mk = (MODE == 1 && a.maskh) ? a.maskh + (MAP ? 0 : (long)p * NPIX * COUT) : nullptr;
     uint4 mv[ITER];
     if (mk) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int c = min(tid + it * NT, TOTAL - 1);
-        mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
+        if constexpr (MAP) {  // the mask plane is a map too: the chunk of the (clamped) output pixel
+          const int oy = min(ty0 + (c / NCH) / IMG_W, a.mh - 1), ox = min(tx0 + (c / NCH) % IMG_W, a.mw - 1);
+          mv[it] = *reinterpret_cast<const uint4 *>(mk + (((long)p * a.mh + oy) * a.mw + ox) * COUT + 8 * (c % NCH));
+        } else {
+          mv[it] = *reinterpret_cast<const uint4 *>(mk + (long)c * 8);
+        }
       }
     }
     for (int pl = 0; pl < NPL; ++pl) {
@@ -538,6 +550,8 @@ struct WgradArgs {
   int P, patches_per_block;
   int xcd_map;                // 1: XCD-aware id -> (slice, group) mapping (needs the slice count to be a multiple of 8)
   long long *stamps;          // `make STAMPS=1`: [workgroup][64]: 4 phase sums over the slice, then k-loop start times
+  // MAP variant only: planes are feature maps [P][mh][mw][C]; the unit of work is (patch, 10x10 tile), P counts units
+  int mh, mw, tiles_x, tiles_y;
 };
 
 template <int IMM>
@@ -591,7 +605,10 @@ constexpr int WG_NCO = 64, YROWS = NPIX + 1;
 //   dY: [100 pixel rows][zero row][8 tail rows = old pixels 92..99].
 constexpr int XTAIL = 2 * PAD_W, TAILPIX = 8, YROWS_ALL = YROWS + TAILPIX;
 
-template <int SPLIT, int CIN, int COUT, int NCI, int NW>
+// MAP = true: feature maps of any size.  A unit is (patch, 10x10 output tile): its X operand is the 12x12 window around
+// the tile gathered from the map (real neighbours in the halo, zeros outside the map), its dY operand the tile's pixels (zero
+// outside the map); every unit is 4 k-steps on its own (no streaming across units: the halo is not zero there).
+template <int SPLIT, int CIN, int COUT, int NCI, int NW, bool MAP = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int NCO = WG_NCO, NTH = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
@@ -745,7 +762,54 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
   uint4 tv[TIT];
 #pragma unroll
   for (int i = 0; i < TIT; ++i) tv[i] = uint4{0, 0, 0, 0};
-  for (int p = p_begin; p < p_end; ++p) {
+  if constexpr (MAP) {
+    const int ntile = a.tiles_x * a.tiles_y;
+    constexpr int WTOT = NPAD * XCH, WIT = (WTOT + NTH - 1) / NTH;
+    for (int u = p_begin; u < p_end; ++u) {
+      const int pq = u / ntile, tile = u % ntile;
+      const int ty0 = (tile / a.tiles_x) * IMG_W, tx0 = (tile % a.tiles_x) * IMG_W;
+      __syncthreads();  // previous unit fully consumed
+      // plane by plane (one round trip each; this path is not the headline shape, registers stay low)
+      for (int pl = 0; pl < NPL; ++pl) {
+        uint4 xv[WIT];
+        const uint16_t *src = (pl ? a.xl : a.xh) + ci_base;
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+          const int c = min(tid + i * NTH, WTOT - 1), wp = c / XCH, ch = c % XCH;
+          const int my = ty0 + wp / PAD_W - 1, mx = tx0 + wp % PAD_W - 1;
+          const bool ok = my >= 0 && my < a.mh && mx >= 0 && mx < a.mw;
+          const long off = (((long)pq * a.mh + min(max(my, 0), a.mh - 1)) * a.mw + min(max(mx, 0), a.mw - 1)) * CIN + 8 * ch;
+          xv[i] = *reinterpret_cast<const uint4 *>(src + off);  // unconditional, clamped (see PlaneLoad)
+          if (!ok) xv[i] = uint4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+          const int c = tid + i * NTH;
+          if (WTOT % NTH == 0 || c < WTOT) *reinterpret_cast<uint4 *>(xs + pl * XPL + (XTAIL + c / XCH) * XS + 16 * (c % XCH)) = xv[i];
+        }
+        uint4 yv[YIT];
+        const uint16_t *ysrc = (pl ? a.dyl : a.dyh) + co_base;
+#pragma unroll
+        for (int i = 0; i < YIT; ++i) {
+          const int c = min(tid + i * NTH, YTOT - 1), pix = c / YCH, ch = c % YCH;
+          const int oy = ty0 + pix / IMG_W, ox = tx0 + pix % IMG_W;
+          const bool ok = oy < a.mh && ox < a.mw;
+          const long off = (((long)pq * a.mh + min(oy, a.mh - 1)) * a.mw + min(ox, a.mw - 1)) * COUT + 8 * ch;
+          yv[i] = *reinterpret_cast<const uint4 *>(ysrc + off);
+          if (!ok) yv[i] = uint4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < YIT; ++i) {
+          const int c = tid + i * NTH;
+          if (YTOT % NTH == 0 || c < YTOT) *reinterpret_cast<uint4 *>(ys + pl * YPL + (c / YCH) * YS + 16 * (c % YCH)) = yv[i];
+        }
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) kstep(ks, 0, false);  // pixels 0..127: rows >= 100 read the zero dY row
+    }
+  }
+  for (int p = MAP ? p_end : p_begin; p < p_end; ++p) {
     __syncthreads();  // previous patch fully consumed (its tail rows are in tv[])
     WG_STAMP(3)
     {
@@ -1230,14 +1294,15 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float *__restrict
 
 // dY[p][i][c] = dgap[p][c] / 100 where the forward output was positive (ReLU)
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ dgap, const uint16_t *__restrict__ yh,
-                                                      int P, int C, uint16_t *dh, uint16_t *dl) {
-  const long n = (long)P * NPIX * C;
+                                                      int P, int C, int npix, uint16_t *dh, uint16_t *dl) {
+  const long n = (long)P * npix * C;
+  const float inv = 1.0f / (float)npix;  // (npix = 100: the same constant the fused loaders multiply by)
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
 #pragma clang fp contract(off)  // same rounding as the fused loaders
     const int c = e % C;
-    const long p = e / ((long)C * NPIX);
+    const long p = e / ((long)C * npix);
     float v = 0.f;
-    if ((yh[e] & 0x7fff) != 0) v = dgap[p * C + c] * (1.0f / NPIX);
+    if ((yh[e] & 0x7fff) != 0) v = dgap[p * C + c] * inv;
     const uint16_t h = f2bf(v);
     dh[e] = h;
     if (dl) dl[e] = f2bf(v - bf2f(h));
@@ -1267,20 +1332,20 @@ int launch_conv_nw(const ConvArgs &a, hipStream_t s) {
   return check_launch();
 }
 
-template <int SPLIT, int CIN, int COUT>
+template <int SPLIT, int CIN, int COUT, int MODE = 0>
 int launch_conv_map(const ConvArgs &a, hipStream_t s) {
   constexpr int CMAX = CIN > COUT ? CIN : COUT, NW = (SPLIT == 3 ? 8 : 4);
   const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * NPAD * row_stride<CMAX>();
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, 0, NW, true>,
+    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, 0, NW, true>), dim3(a.P * a.tiles_x * a.tiles_y), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW, true>), dim3(a.P * a.tiles_x * a.tiles_y), dim3(NW * 64), lds, s, a);
   return check_launch();
 }
 
@@ -1315,6 +1380,24 @@ int launch_wgrad(const WgradArgs &a, int nblk, hipStream_t s) {
     attr = true;
   }
   hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI, NW>), dim3(nblk * (CIN / NCI) * (COUT / WG_NCO)),
+                     dim3(NW * 64), lds, s, a);
+  return check_launch();
+}
+
+template <int SPLIT, int CIN, int COUT>
+int launch_wgrad_map(const WgradArgs &a, int nblk, hipStream_t s) {
+  constexpr int NCI = wgrad_nci(CIN), NW = SPLIT == 3 ? 4 : 8;
+  const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * ((XTAIL + NPAD) * row_stride<NCI>() + YROWS_ALL * row_stride<WG_NCO>());
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI, NW, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<SPLIT, CIN, COUT, NCI, NW, true>), dim3(nblk * (CIN / NCI) * (COUT / WG_NCO)),
                      dim3(NW * 64), lds, s, a);
   return check_launch();
 }
@@ -1380,32 +1463,36 @@ int crw_enc_pack_input_map(const float *x, int P, int C, int H, int W, uint16_t 
   return check_launch();
 }
 
-int crw_enc_conv3x3_map(int split, int P, int H, int W, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
-                        const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, uint16_t *y_hi, uint16_t *y_lo,
-                        float *gap_part, crw_stream_t stream) {
+int crw_enc_conv3x3_map(int mode, int split, int P, int H, int W, int cin, int cout, const uint16_t *x_hi, const uint16_t *x_lo,
+                        const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, const uint16_t *mask_hi, uint16_t *y_hi,
+                        uint16_t *y_lo, float *y_f32, float *gap_part, crw_stream_t stream) {
   clear_stale_error();
-  if (!x_hi || !w_hi || P < 1 || H < 1 || W < 1 || (split != 1 && split != 3)) return CRW_EINVAL;
+  if (!x_hi || !w_hi || P < 1 || H < 1 || W < 1 || (split != 1 && split != 3) || (mode != 0 && mode != 1)) return CRW_EINVAL;
   if (split == 3 && (!w_lo || !x_lo)) return CRW_EINVAL;
-  if (!y_hi && !gap_part) return CRW_EINVAL;
+  if (!y_hi && !gap_part && !y_f32) return CRW_EINVAL;
+  if (mode == 1 && (gap_part || bias)) return CRW_EINVAL;
   const int tx = (W + IMG_W - 1) / IMG_W, ty = (H + IMG_W - 1) / IMG_W;
   if ((long)P * tx * ty > 0x7fffffffL) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, nullptr, y_hi, y_lo, nullptr, gap_part, nullptr, P, nullptr, H, W, tx, ty};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap_part, nullptr, P, nullptr, H, W, tx, ty};
   hipStream_t s = (hipStream_t)stream;
-#define CRW_MAP_CASE(CI, CO) \
-  if (cin == CI && cout == CO) return split == 3 ? launch_conv_map<3, CI, CO>(a, s) : launch_conv_map<1, CI, CO>(a, s);
-  CRW_MAP_CASE(32, 64)
-  CRW_MAP_CASE(64, 128)
-  CRW_MAP_CASE(128, 128)
+#define CRW_MAP_CASE(CI, CO, MODE) \
+  if (mode == MODE && cin == CI && cout == CO) return split == 3 ? launch_conv_map<3, CI, CO, MODE>(a, s) : launch_conv_map<1, CI, CO, MODE>(a, s);
+  CRW_MAP_CASE(32, 64, 0)
+  CRW_MAP_CASE(64, 128, 0)
+  CRW_MAP_CASE(128, 128, 0)
+  CRW_MAP_CASE(128, 128, 1)
+  CRW_MAP_CASE(128, 64, 1)
+  CRW_MAP_CASE(64, 32, 1)
 #undef CRW_MAP_CASE
   return CRW_EINVAL;
 }
 
-int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, uint16_t *dy_hi, uint16_t *dy_lo,
+int crw_enc_gap_bwd(const float *dgap, const uint16_t *y_hi, int P, int C, int npix, uint16_t *dy_hi, uint16_t *dy_lo,
                     crw_stream_t stream) {
   clear_stale_error();
-  if (!dgap || !y_hi || !dy_hi || P < 1 || C < 1) return CRW_EINVAL;
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid((long)P * NPIX * C)), dim3(256), 0, (hipStream_t)stream, dgap, y_hi, P,
-                     C, dy_hi, dy_lo);
+  if (!dgap || !y_hi || !dy_hi || P < 1 || C < 1 || npix < 1) return CRW_EINVAL;
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid((long)P * npix * C)), dim3(256), 0, (hipStream_t)stream, dgap, y_hi, P,
+                     C, npix, dy_hi, dy_lo);
   return check_launch();
 }
 
@@ -1468,7 +1555,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   int ppb = (P + nslice - 1) / nslice;
   if (streamed) nslice = (P + ppb - 1) / ppb;  // no empty slices: every slab is written
   float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
-  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, nslice % 8 == 0 ? 1 : 0, g_conv_stamps};
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, dgap, dw_part, db_part, P, ppb, nslice % 8 == 0 ? 1 : 0, g_conv_stamps, 0, 0, 1, 1};
   int st = CRW_EINVAL;
   if (streamed) {
     if (cin == 64) st = split == 3 ? launch_wgrad2<3, 64, 128>(a, nslice, s) : launch_wgrad2<1, 64, 128>(a, nslice, s);
@@ -1489,6 +1576,41 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
   CRW_WG_CASE(128, 128)
 #undef CRW_WG_CASE
   }
+  if (st != CRW_OK) return st;
+  const long nw = (long)cout * cin * 9;
+  const int nblk_dw = (int)((nw + 63) / 64);
+  hipLaunchKernelGGL(slice_sum_dw_kernel, dim3((unsigned)(nblk_dw + (cout + 3) / 4)), dim3(256), 0, s, dw_part, nslice, cout * cin,
+                     dw, nblk_dw, db_part, cout, db);
+  return check_launch();
+}
+
+
+/* weight / bias gradient of one 3x3 layer on feature maps of any size: dY [P][H][W][cout], X [P][H][W][cin] planes.
+ * ws: crw_enc_wgrad_ws_bytes(P * ceil(H/10) * ceil(W/10), cin, cout, split). */
+int crw_enc_conv3x3_wgrad_map(int split, int P, int H, int W, int cin, int cout, const uint16_t *dy_hi, const uint16_t *dy_lo,
+                              const uint16_t *x_hi, const uint16_t *x_lo, float *dw, float *db, void *ws, size_t ws_bytes,
+                              crw_stream_t stream) {
+  clear_stale_error();
+  if (!dy_hi || !x_hi || !dw || !db || !ws || P < 1 || H < 1 || W < 1 || (split != 1 && split != 3)) return CRW_EINVAL;
+  if (split == 3 && (!dy_lo || !x_lo)) return CRW_EINVAL;
+  const int tx = (W + IMG_W - 1) / IMG_W, ty = (H + IMG_W - 1) / IMG_W;
+  const long units_l = (long)P * tx * ty;
+  if (units_l > 0x7fffffffL) return CRW_EINVAL;
+  const int units = (int)units_l;
+  if (ws_bytes < crw_enc_wgrad_ws_bytes(units, cin, cout, split)) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int nslice = wgrad_slices(units, cin, cout, split);
+  const int upb = (units + nslice - 1) / nslice;
+  nslice = (units + upb - 1) / upb;  // no empty slices: every slab is written
+  float *dw_part = static_cast<float *>(ws), *db_part = dw_part + (size_t)nslice * cout * cin * 9;
+  WgradArgs a{dy_hi, dy_lo, x_hi, x_lo, nullptr, dw_part, db_part, units, upb, nslice % 8 == 0 ? 1 : 0, nullptr, H, W, tx, ty};
+  int st = CRW_EINVAL;
+#define CRW_WGM_CASE(CI, CO) \
+  if (cin == CI && cout == CO) st = split == 3 ? launch_wgrad_map<3, CI, CO>(a, nslice, s) : launch_wgrad_map<1, CI, CO>(a, nslice, s);
+  CRW_WGM_CASE(32, 64)
+  CRW_WGM_CASE(64, 128)
+  CRW_WGM_CASE(128, 128)
+#undef CRW_WGM_CASE
   if (st != CRW_OK) return st;
   const long nw = (long)cout * cin * 9;
   const int nblk_dw = (int)((nw + 63) / 64);

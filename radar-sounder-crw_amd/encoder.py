@@ -8,8 +8,10 @@ conv1-ReLU-pool-conv2-ReLU-pool (csrc/encoder_front.hip), the 3x3 layers conv3/c
 and the global average pool (csrc/encoder_conv.hip), forward AND backward -- runs in hand-written
 HIP kernels (``CNN.hip_convs``: "bf16x3" = hi/lo bf16 operand pairs on the matrix cores, fp32-grade
 results, the default; "bf16" = plain bf16 operands; None = PyTorch-ROCm ops).  Only the linear
-head stays a PyTorch op.  At other patch sizes, inference (``torch.no_grad``) runs conv3-5 + pooling on the tiled
-HIP kernels (``_hip_inference_trunk``) and training uses PyTorch ops; CPU tensors and ``Resnet`` use PyTorch ops.
+head stays a PyTorch op.  At other patch sizes the 3x3 trunk runs on the tiled variants of the same kernels (10x10 output
+tiles over the feature map): inference (``torch.no_grad``) the whole trunk incl. the front end (``_hip_inference_trunk``);
+training conv3-5 + pooling forward, backward-data and weight gradients (``_HipMapTrunk``), with the small front end on
+PyTorch-ROCm ops.  CPU tensors and ``Resnet`` use PyTorch ops (a CUDA batch that misses the HIP path warns once).
 """
 import warnings
 
@@ -67,6 +69,47 @@ class _HipEncoder(torch.autograd.Function):
         dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3)
         return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
+class _HipMapTrunk(torch.autograd.Function):
+    """conv3 / conv4 / conv5 (+ReLU) and the global average pool on feature maps of ANY size (training at patch sizes other
+    than 16x16, e.g. the 32x32 patches of BASELINE config 5): forward, backward-data and weight gradients all on the tiled
+    HIP kernels (10x10 output tiles over the map: `crw_enc_conv3x3_map`, `crw_enc_conv3x3_wgrad_map`, `crw_enc_gap_bwd`).
+    a2 [P,32,H,W] fp32 (output of the front end) -> pooled features [P,128]; the gradient with respect to a2 is returned, so
+    the front end (conv1 / pool / conv2 / pool, 3 % of the encoder's flops) trains through PyTorch autograd at these sizes."""
+
+    @staticmethod
+    def forward(ctx, a2, w3, b3, w4, b4, w5, b5, split):
+        import crw_hip
+        P, _, H, W = a2.shape
+        packed = [crw_hip.enc_pack_weights(w, split) for w in (w3, w4, w5)]
+        x3h, x3l = crw_hip.enc_pack_input_map(a2.contiguous(), split)
+        y3h, y3l, _ = crw_hip.enc_conv3x3_map(split, x3h, x3l, packed[0][0], packed[0][1], 64, H, W, bias=b3)
+        y4h, y4l, _ = crw_hip.enc_conv3x3_map(split, y3h, y3l, packed[1][0], packed[1][1], 128, H, W, bias=b4)
+        y5h, _, gap = crw_hip.enc_conv3x3_map(split, y4h, y4l, packed[2][0], packed[2][1], 128, H, W, bias=b5, gap=True,
+                                              lo_plane=False)  # only the sign of y5 is needed later
+        ctx.split, ctx.hw = split, (H, W)
+        ctx.save_for_backward(x3h, x3l, y3h, y3l, y4h, y4l, y5h, *[t for pk in packed for t in (pk[2], pk[3])])
+        return gap
+
+    @staticmethod
+    def backward(ctx, dgap):
+        import crw_hip
+        s, (H, W) = ctx.split, ctx.hw
+        sv = ctx.saved_tensors
+        x3h, x3l, y3h, y3l, y4h, y4l, y5h = sv[:7]
+        bw = [(sv[7], sv[8]), (sv[9], sv[10]), (sv[11], sv[12])]
+        d5h, d5l = crw_hip.enc_gap_bwd(dgap.contiguous().float(), y5h, s)               # ReLU5 + GAP backward
+        dw5, db5 = crw_hip.enc_wgrad_map(s, d5h, d5l, y4h, y4l, H, W)
+        d4h, d4l, _ = crw_hip.enc_conv3x3_map(s, d5h, d5l, *bw[2], 128, H, W, mode=1, mask=y4h)
+        dw4, db4 = crw_hip.enc_wgrad_map(s, d4h, d4l, y3h, y3l, H, W)
+        d3h, d3l, _ = crw_hip.enc_conv3x3_map(s, d4h, d4l, *bw[1], 64, H, W, mode=1, mask=y3h)
+        dw3, db3 = crw_hip.enc_wgrad_map(s, d3h, d3l, x3h, x3l, H, W)
+        da2 = None
+        if ctx.needs_input_grad[0]:
+            _, _, dx3 = crw_hip.enc_conv3x3_map(s, d3h, d3l, *bw[0], 32, H, W, mode=1, planes=False, f32=True)  # [P, H*W, 32]
+            da2 = dx3.view(-1, H, W, 32).permute(0, 3, 1, 2)
+        return da2, dw3, db3, dw4, db4, dw5, db5, None
+
+
 class _HipLinear(torch.autograd.Function):
     """The 128 -> 128 head.  Forward and dX are PyTorch matmuls; the weight gradient dW = dy^T x (M = N = 128, K = P)
     runs on `crw_linear128_wgrad`: hipBLASLt gives that shape 16 workgroups (~100 us at P = 16128), the split over P
@@ -121,14 +164,20 @@ class CNN(nn.Module):
                                     c[3].weight, c[3].bias, c[4].weight, c[4].bias,
                                     3 if self.hip_convs == "bf16x3" else 1)
             return self._head(gap)
-        if (self.hip_convs and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-                and min(x.shape[-2:]) >= 7):
-            return self._head(self._hip_inference_trunk(x))
+        if self.hip_convs and x.is_cuda and x.dtype == torch.float32 and min(x.shape[-2:]) >= 7:
+            if not torch.is_grad_enabled():
+                return self._head(self._hip_inference_trunk(x))
+            # training at another patch size: the 3x3 trunk (96.7 % of the flops) forward AND backward on the tiled HIP
+            # kernels, the small front end on PyTorch-ROCm ops with autograd
+            a2 = self.pool2(self.relu2(self.conv2(self.pool1(self.relu1(self.conv1(x))))))
+            gap = _HipMapTrunk.apply(a2, self.conv3.weight, self.conv3.bias, self.conv4.weight, self.conv4.bias,
+                                     self.conv5.weight, self.conv5.bias, 3 if self.hip_convs == "bf16x3" else 1)
+            return self._head(gap)
         if self.hip_convs and x.is_cuda and not CNN._warned_fallback:
             # not silent: the caller believes it is on the hand-written kernels (set hip_convs = None to choose this path)
             CNN._warned_fallback = True
             warnings.warn(f"CNN.forward: input {tuple(x.shape)} {x.dtype} (grad enabled: {torch.is_grad_enabled()}) is not covered by "
-                          "the HIP conv kernels (float32 patches; training needs 16x16 patches, inference >= 7x7): this call "
+                          "the HIP conv kernels (float32 patches of at least 7x7 on an MI355X): this call "
                           "runs on PyTorch-ROCm / MIOpen convolutions", RuntimeWarning, stacklevel=2)
         for name, _, _, pooled in _CNN_STACK:
             x = getattr(self, "relu" + name)(getattr(self, "conv" + name)(x))

@@ -308,10 +308,78 @@ def test_encoder_inference_trunk_any_patch_size(hip, hw, split):
         b = torch.randn(64, generator=g) * 0.1
         fh, fl, _, _ = hip.enc_pack_weights(w.cuda(), 3)
         xh, xl = hip.enc_pack_input_map(xm.cuda(), 3)
-        yh, yl, gap = hip.enc_conv3x3_map(3, xh, xl, fh, fl, 64, 14, 21, bias=b.cuda(), gap=False)
+        yh, yl, gap = hip.enc_conv3x3_map(3, xh, xl, fh, fl, 64, 14, 21, bias=b.cuda(), gap=False)  # (mode 0)
         xq = (xh.float() + xl.float()).cpu().double().reshape(3, 14, 21, 32).permute(0, 3, 1, 2)
         y_ref = TF.relu(TF.conv2d(xq, w.double(), b.double(), padding=1)).permute(0, 2, 3, 1).reshape(3, 14 * 21, 64)
         torch.testing.assert_close((yh.float() + yl.float()).cpu().double(), y_ref, rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("hw,ov", [((32, 32), (24, 0)), ((20, 27), (10, 0))])
+def test_training_at_other_patch_sizes_vs_oracle(hip, hw, ov):
+    """Training step at patch sizes other than 16x16 (BASELINE config 5 is a 32x32-patch model, overlap (24,0),
+    scripts/test/test_mc1.py:19-26): conv3-5 forward, backward-data and weight gradients on the tiled HIP kernels
+    (`_HipMapTrunk`: 26x26 and 14x21 feature maps = 3x3 / 2x3 tiles with partial tiles in both directions), front end through
+    PyTorch autograd, HIP affinity + walk -- loss and every parameter gradient against the fp64 oracle, tolerances of
+    test_full_model_matches_reference."""
+    import warnings
+    import model as crw_model
+    import encoder as crw_encoder
+    import dataset as crw_dataset
+    T = 4
+    h, w = hw
+    ds = crw_dataset.RGDataset.synthetic(ov[0] + 5 * (h - ov[0]), 2 * T * w, T, hw, ov, seed=13)
+    seq = torch.stack([ds[0], ds[T]])                          # [2, T, 5, h, w]
+    torch.manual_seed(11)
+    enc = crw_encoder.CNN(False)
+    sd = {k: v.detach().clone().double().requires_grad_(True) for k, v in enc.state_dict().items()}
+    loss_ref, _, _ = orc.crw_forward_torch(seq.double(), sd, 0.05)
+    loss_ref.backward()
+    net = crw_model.CRW(enc, 0.05, False).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                        # the PyTorch-op fallback would warn: it must not be taken
+        loss, A = net(seq.cuda())
+        loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    for k, p_ in enc.named_parameters():
+        ref = sd[k].grad.float().numpy()
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max(), err_msg=k)
+
+
+@pytest.mark.parametrize("split", [3, 1])
+def test_map_backward_kernels_match_torch(hip, split):
+    """backward-data (with and without ReLU mask, fp32 copy) and weight / bias gradient of one 3x3 layer on a 14x21 map
+    (2 x 3 tiles, partial in both directions) against fp64 torch, and the generic ReLU + average-pool backward."""
+    import torch.nn.functional as TF
+    P, cin, cout, H, W = 3, 64, 128, 14, 21
+    g = torch.Generator().manual_seed(40 + split)
+    hl = lambda t: (t.bfloat16(), (t - t.bfloat16().float()).bfloat16() if split == 3 else None)
+    val = lambda h_, l_: (h_.float() + (l_.float() if l_ is not None else 0)).cpu().double()
+    x = (torch.randn(P, H * W, cin, generator=g) * 0.5).cuda()
+    dy = (torch.randn(P, H * W, cout, generator=g) * 0.5).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    fh, fl, bh, bl = hip.enc_pack_weights(w, split)
+    (xh, xl), (dh, dl) = hl(x), hl(dy)
+    nchw = lambda t, c: t.reshape(P, H, W, c).permute(0, 3, 1, 2)
+    xq, dq = nchw(val(xh, xl), cin), nchw(val(dh, dl), cout)
+    wq = w.bfloat16().float().cpu().double() if split == 1 else w.cpu().double()
+    tol = dict(rtol=5e-5, atol=5e-5) if split == 3 else dict(rtol=3e-2, atol=3e-2)
+    dx_ref = TF.conv_transpose2d(dq, wq, padding=1)                       # [P, cin, H, W]
+    mask = (torch.rand(P, H * W, cin, generator=g) > 0.4).float().cuda().bfloat16()
+    mh_, ml_, mf = hip.enc_conv3x3_map(split, dh, dl, bh, bl, cin, H, W, mode=1, mask=mask, f32=True)
+    full = dx_ref.permute(0, 2, 3, 1).reshape(P, H * W, cin)
+    torch.testing.assert_close(mf.cpu().double(), full, **tol)                      # the fp32 copy is the unmasked gradient
+    torch.testing.assert_close(val(mh_, ml_), full * mask.float().cpu().double(), **tol)   # the planes carry the ReLU mask
+    _, _, uf = hip.enc_conv3x3_map(split, dh, dl, bh, bl, cin, H, W, mode=1, planes=False, f32=True)
+    torch.testing.assert_close(uf.cpu().double(), dx_ref.permute(0, 2, 3, 1).reshape(P, H * W, cin), **tol)
+    dw, db = hip.enc_wgrad_map(split, dh, dl, xh, xl, H, W)
+    dw_ref = torch.nn.grad.conv2d_weight(xq, w.shape, dq, padding=1)
+    wtol = dict(rtol=1e-4, atol=1e-4 * dw_ref.abs().max().item()) if split == 3 else dict(rtol=5e-2, atol=2e-2 * dw_ref.abs().max().item())
+    torch.testing.assert_close(dw.cpu().double(), dw_ref, **wtol)
+    torch.testing.assert_close(db.cpu().double(), dq.sum((0, 2, 3)), **wtol)
+    dgap = torch.randn(P, cin, generator=g).cuda()
+    gh, gl = hip.enc_gap_bwd(dgap, xh, split)
+    want_g = (dgap.cpu().double()[:, None, :] / (H * W)) * (val(xh, None) != 0)
+    torch.testing.assert_close(val(gh, gl), want_g, rtol=1e-5 if split == 3 else 1e-2, atol=1e-7 if split == 3 else 1e-4)
 
 
 @pytest.mark.parametrize("convs", ["bf16x3", "bf16"])
