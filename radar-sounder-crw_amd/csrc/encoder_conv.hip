@@ -959,12 +959,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
 //     k-step n + 1 (32 dY rows; and, where a new patch begins at k-step n + 2 / n + 1, the hi / lo plane of its X
 //     image), computes k-step n, then stores the staged registers to LDS; ONE barrier per k-step.  A slot is only
 //     written a full k-step after its last reader (see the schedule in the kernel).
+//   * Measured and NOT kept: the same kernel with LDS-DMA staging (global_load_lds two k-steps ahead into a three-slot dY ring
+//     and 16-pitch X images, source-side swizzles, counted vmcnt + raw barrier, no staging registers): parity-green, 1123 us
+//     against 1073 us for this register-staged form (conv5, P = 16128; in-step 1205 vs 1070) -- 3.6 DMA issues and ~150
+//     address VALU per wave and k-step cost more than the staging they replace.  What the staging costs here: CRW_WGRAD_DIAG.
 //   * Rows of a k-step are dealt to the lane groups by parity (half-wave 0: even rows, half-wave 1: odd rows): on the
 //     2C+16 row stride eight same-parity rows start in eight different bank octets (consecutive rows collide 2-way).
 constexpr int W2_NCO = 128, W2_NCI = 64, W2_NW = 8, W2_KROWS = 32;
 
-// DIAG (timing-only diagnostic builds of the conv5 shape, CRW_WGRAD_DIAG=1|2|3; results are wrong): 1 = no barrier in the k-loop,
-// 2 = no staging (no global loads, no LDS stores), 3 = both -- what the k-loop costs without its pipeline partners
+// DIAG (timing-only diagnostic builds of the conv5 shape, CRW_WGRAD_DIAG=1..5; results are wrong): 1 = no barrier in the k-loop,
+// 2 = no staging (no global loads, no LDS stores), 3 = both, 4 = global loads but no LDS stores, 5 = LDS stores but no global
+// loads -- what the k-loop costs without its pipeline partners
 template <int SPLIT, int CIN, int COUT, int DIAG = 0>
 __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
   constexpr int NCO = W2_NCO, NCI = W2_NCI, NTH = W2_NW * 64, NPL = (SPLIT == 3) ? 2 : 1;
@@ -1172,13 +1177,18 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
     const int xq = q_lo >= 0 ? q_lo : q_hi, xpl = q_lo >= 0 ? NPL - 1 : 0;
     // the loads are UNCONDITIONAL (clamped): a load under a run-time condition makes hipcc wait for it on the spot (the
     // value is merged with the not-taken path), which would serialise a memory round trip into every k-step
-    if (!(DIAG & 2)) {
+    if (DIAG != 2 && DIAG != 3 && DIAG != 5) {
       load_dy(more ? n + 1 : n);
       load_x(xq >= 0 ? xq : 0, xpl);
     }
     kstep(n);
-    if (DIAG & 2) {
+    if (DIAG == 2 || DIAG == 3) {
       if (DIAG & 1) continue;
+      __syncthreads();
+      continue;
+    }
+    if (DIAG == 4) {  // keep the loaded registers alive without storing them
+      asm volatile("" ::"v"(sy[0].x), "v"(sy[NPL - 1].y), "v"(sx[0].x), "v"(sx[1].y));
       __syncthreads();
       continue;
     }
@@ -1565,6 +1575,8 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
       if (diag && split == 3 && diag[0] == '1') return launch_wgrad2<3, 128, 128, 1>(a, nslice, s);
       if (diag && split == 3 && diag[0] == '2') return launch_wgrad2<3, 128, 128, 2>(a, nslice, s);
       if (diag && split == 3 && diag[0] == '3') return launch_wgrad2<3, 128, 128, 3>(a, nslice, s);
+      if (diag && split == 3 && diag[0] == '4') return launch_wgrad2<3, 128, 128, 4>(a, nslice, s);
+      if (diag && split == 3 && diag[0] == '5') return launch_wgrad2<3, 128, 128, 5>(a, nslice, s);
 #endif
       st = split == 3 ? launch_wgrad2<3, 128, 128>(a, nslice, s) : launch_wgrad2<1, 128, 128>(a, nslice, s);
     }

@@ -184,8 +184,6 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
-        // (priority pair around the cluster: keeps hipcc from sinking MFMAs across the barrier in among the next tile's DMA issue)
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < AG; ++i)
 #pragma unroll
@@ -196,7 +194,6 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
             }
             acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i0 + i][j], 0, 0, 0);
           }
-        __builtin_amdgcn_s_setprio(0);
       }
     }
   }
