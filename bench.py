@@ -449,13 +449,14 @@ def main():
             split = 3 if args.convs == "bf16x3" else 1
             P = B * T * N
             names = {"fwd": "conv3x3_kernel fwd (bias+ReLU)", "bwd": "conv3x3_kernel bwd-data (+ReLU mask)",
-                     "wgrad": "conv3x3_wgrad_kernel (+ slice sum)"}
+                     "wgrad": "conv3x3_wgrad2_kernel / conv3x3_wgrad_kernel (+ slice sum)"}
             for (kind, cin, cout), pairs in sorted(ev.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
                 kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
                 alg = 2.0 * P * 100 * cin * cout * 9  # algorithmic flops of one pass over one layer
-                pad = (10 * 32 / 3) / 100.0 if kind == "wgrad" else 112.0 / 100.0  # MFMA padding of the pixel dim: the weight
-                # gradient streams k-steps across patches (10 k-steps of 32 pixels per 3 patches), forward / backward-data
-                # run 7 row tiles of 16 per patch
+                # MFMA padding of the pixel dim: forward / backward-data run 7 row tiles of 16 per patch; the streamed weight gradient
+                # (128 output channels) takes its k-steps of 32 pixels over the whole pixel stream of a slice, the first-generation
+                # kernel (conv3's 64 output channels) 10 k-steps per 3 patches
+                pad = (1.0 if cout == 128 else (10 * 32 / 3) / 100.0) if kind == "wgrad" else 112.0 / 100.0
                 kernels.append({"kernel": f"{names[kind]} cin={cin} cout={cout}", "bound": "mfma",
                                 "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
                                 "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
@@ -476,35 +477,37 @@ def main():
                             "note": "launch-latency bound at the reference-default node count"})
         # HBM traffic per launch from the committed PMC passes over this same command (rocprofv3 cannot run inside bench)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_in_step_traffic.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_in_step_traffic.json")))["kernels"]
             for k in kernels:
                 m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
                 if not m or args.convs != "bf16x3" or B * T * N != 16128:  # the passes ran at the default workload
                     continue
                 cin, cout = int(m.group(1)), int(m.group(2))
-                key = (f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4>" if "wgrad" in k["kernel"] else
+                key = ((f"conv3x3_wgrad2_kernel<3, {cin}, {cout}, 0>" if cout == 128 else
+                        f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4, false>") if "wgrad" in k["kernel"] else
                        f"conv3x3_kernel<3, {cout}, {cin}, 1, {4 if cin == 32 else 8}, false>" if "bwd-data" in k["kernel"] else
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
                 if key in pmc:
                     k["traffic"] = pmc[key]["hbm_bytes"]
-                    k["traffic_note"] = ("HBM bytes per launch INSIDE the step, committed PMC passes profiles/r01_pmc_in_step_traffic.json: "
+                    k["traffic_note"] = ("HBM bytes per launch INSIDE the step, committed PMC passes profiles/r02_pmc_in_step_traffic.json: "
                                          "reads = 2*1024*FETCH_SIZE (gfx950 correction) + writes = 1024*WRITE_SIZE; read/algorithmic = "
                                          f"{pmc[key]['read_over_algorithmic']}"
                                          + (f", write/algorithmic = {pmc[key]['write_over_algorithmic']}"
                                             if "write_over_algorithmic" in pmc[key] else ""))
-            util = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_in_step.json")))["kernels"]
+            util = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_in_step.json")))["kernels"]
             for k in kernels:
                 m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
                 if not m or args.convs != "bf16x3" or B * T * N != 16128:
                     continue
                 cin, cout = int(m.group(1)), int(m.group(2))
-                key = (f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4>" if "wgrad" in k["kernel"] else
+                key = ((f"conv3x3_wgrad2_kernel<3, {cin}, {cout}, 0>" if cout == 128 else
+                        f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4, false>") if "wgrad" in k["kernel"] else
                        f"conv3x3_kernel<3, {cout}, {cin}, 1, {4 if cin == 32 else 8}, false>" if "bwd-data" in k["kernel"] else
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
                 if key in util:
                     k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
                     k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
-                    k["pmc_note"] = ("committed PMC pass over this same command (profiles/r01_pmc_in_step.json): "
+                    k["pmc_note"] = ("committed PMC pass over this same command (profiles/r02_pmc_in_step.json): "
                                      "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) and the clock the chip held "
                                      "under this kernel inside the step (nominal 2.4 GHz)")
         except Exception:

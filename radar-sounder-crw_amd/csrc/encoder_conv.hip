@@ -1032,8 +1032,9 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
   uint4 sy[NPL], sx[2];
   auto load_dy = [&](int n) {  // the 32 rows of k-step n; rows past the stream are out of the descriptor's range: zeros
     const int soff = n * (W2_KROWS * COUT * 2);
-    sy[0] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(dyh_rs, y_voff, soff, 0));
-    if (SPLIT == 3 && !a.dgap) sy[NPL - 1] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(dyl_rs, y_voff, soff, 0));
+    constexpr int AUX = DIAG == 6 ? 2 : 0;  // DIAG 6: non-temporal policy on the staged loads (results stay correct)
+    sy[0] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(dyh_rs, y_voff, soff, AUX));
+    if (SPLIT == 3 && !a.dgap) sy[NPL - 1] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(dyl_rs, y_voff, soff, AUX));
   };
   auto store_dy = [&](int n) {
     uint4 vh = sy[0], vl = uint4{0, 0, 0, 0};
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
     const int soff = q * (NPIX * CIN * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      sx[i] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(pl ? xl_rs : xh_rs, x_voff[i], soff, 0));
+      sx[i] = __builtin_bit_cast(uint4, (u4v)__builtin_amdgcn_raw_buffer_load_b128(pl ? xl_rs : xh_rs, x_voff[i], soff, DIAG == 6 ? 2 : 0));
   };
   auto store_x = [&](int q, int pl) {
     char *dst = xs + (q & 1) * XSLOT + pl * XPL;
@@ -1577,6 +1578,7 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
       if (diag && split == 3 && diag[0] == '3') return launch_wgrad2<3, 128, 128, 3>(a, nslice, s);
       if (diag && split == 3 && diag[0] == '4') return launch_wgrad2<3, 128, 128, 4>(a, nslice, s);
       if (diag && split == 3 && diag[0] == '5') return launch_wgrad2<3, 128, 128, 5>(a, nslice, s);
+      if (diag && split == 3 && diag[0] == '6') return launch_wgrad2<3, 128, 128, 6>(a, nslice, s);
 #endif
       st = split == 3 ? launch_wgrad2<3, 128, 128>(a, nslice, s) : launch_wgrad2<1, 128, 128>(a, nslice, s);
     }
