@@ -449,14 +449,20 @@ def main():
             split = 3 if args.convs == "bf16x3" else 1
             P = B * T * N
             names = {"fwd": "conv3x3_kernel fwd (bias+ReLU)", "bwd": "conv3x3_kernel bwd-data (+ReLU mask)",
+                     "front_fwd": "front_fwd_kernel (conv1-pool-conv2-pool, saves pool1 planes + pooling codes)",
+                     "front_bwd": "front_bwd_saved_kernel (+ slice sum)",
                      "wgrad": "conv3x3_wgrad2_kernel / conv3x3_wgrad_kernel (+ slice sum)"}
             for (kind, cin, cout), pairs in sorted(ev.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
                 kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
                 alg = 2.0 * P * 100 * cin * cout * 9  # algorithmic flops of one pass over one layer
+                if kind.startswith("front"):  # conv1 (196 outputs x 8 ch x 25 cin taps) + conv2 (121 x 32 x 200), x2 for the backward
+                    alg = 2.0 * P * (196 * 8 * 25 * cin + 121 * 32 * 200) * (2 if kind == "front_bwd" else 1)
                 # MFMA padding of the pixel dim: forward / backward-data run 7 row tiles of 16 per patch; the streamed weight gradient
                 # (128 output channels) takes its k-steps of 32 pixels over the whole pixel stream of a slice, the first-generation
                 # kernel (conv3's 64 output channels) 10 k-steps per 3 patches
                 pad = (1.0 if cout == 128 else (10 * 32 / 3) / 100.0) if kind == "wgrad" else 112.0 / 100.0
+                if kind.startswith("front"):
+                    pad = 1.0
                 kernels.append({"kernel": f"{names[kind]} cin={cin} cout={cout}", "bound": "mfma",
                                 "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
                                 "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],

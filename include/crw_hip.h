@@ -182,22 +182,26 @@ int crw_enc_conv3x3_wgrad(int split, int P, int cin, int cout, const uint16_t *d
 /* conv2 weight [32][8][5][5] fp32 -> forward planes [7][32][32] and backward planes [25][8][32] */
 int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi, uint16_t *bwd_lo,
                        crw_stream_t stream);
-/* x [P][cin][16][16] fp32 -> planes [P][100][32] (input of crw_enc_conv3x3 cin = 32) */
+/* x [P][cin][16][16] fp32 -> planes [P][100][32] (input of crw_enc_conv3x3 cin = 32).
+ * saved (may be NULL; training): crw_enc_front_saved_bytes(P) bytes that receive, per patch, the pool1 output planes and one
+ * code byte per pooling window (arg-max position + ReLU gate); crw_enc_front_bwd then needs no recomputation. */
+size_t crw_enc_front_saved_bytes(int P);
 int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
                       const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi,
-                      uint16_t *y_lo, crw_stream_t stream);
+                      uint16_t *y_lo, void *saved, crw_stream_t stream);
 /* The same front end on patches of any size h, w >= 7 (forward only, inference): x [P][cin][H][W] -> planes
  * [P][(H-6)*(W-6)][32] that feed crw_enc_conv3x3_map.  Work item = (patch, 10x10 tile of the output map). */
 int crw_enc_front_fwd_map(int split, const float *x, int P, int cin, int H, int W, const float *w1, const float *b1,
                           const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi, uint16_t *y_lo,
                           crw_stream_t stream);
-/* backward (recomputes the forward per patch): dy [P][100][32] fp32 -> dw1 [8][cin][5][5], db1 [8],
- * dw2 [32][8][5][5], db2 [32]; partial sums per patch slice in `ws`, added in a fixed order. */
+/* backward: dy [P][100][32] fp32 -> dw1 [8][cin][5][5], db1 [8], dw2 [32][8][5][5], db2 [32]; partial sums per patch
+ * slice in `ws`, added in a fixed order.  saved: the record crw_enc_front_fwd wrote for these patches, or NULL (the kernel
+ * then recomputes conv1 -> pool1 -> conv2 per patch; same results, ~40 % more time). */
 size_t crw_enc_front_ws_bytes(int P, int cin);
 int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
                       const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const uint16_t *w2b_hi,
-                      const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2,
-                      void *ws, size_t ws_bytes, crw_stream_t stream);
+                      const uint16_t *w2b_lo, const float *dy, const void *saved, float *dw1, float *db1, float *dw2,
+                      float *db2, void *ws, size_t ws_bytes, crw_stream_t stream);
 
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous

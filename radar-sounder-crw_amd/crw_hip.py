@@ -49,10 +49,11 @@ SIGNATURES = {
     "crw_enc_wgrad_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "crw_enc_conv3x3_wgrad": (_c_int, [_c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_enc_front_pack": (_c_int, [_p, _p, _p, _p, _p, _p]),
-    "crw_enc_front_fwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "crw_enc_front_saved_bytes": (_c_sz, [_c_int]),
+    "crw_enc_front_fwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_front_fwd_map": (_c_int, [_c_int, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "crw_enc_front_ws_bytes": (_c_sz, [_c_int, _c_int]),
-    "crw_enc_front_bwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+    "crw_enc_front_bwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _c_sz, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
@@ -386,15 +387,19 @@ def enc_front_pack(w2, split):
     return fh, fl, bh, bl
 
 
-def enc_front_fwd(split, x, w1, b1, w2f, b2):
-    """x [P,cin,16,16] -> planes [P,100,32] (conv1-ReLU-pool-conv2-ReLU-pool)."""
+def enc_front_fwd(split, x, w1, b1, w2f, b2, save=False):
+    """x [P,cin,16,16] -> planes [P,100,32] (conv1-ReLU-pool-conv2-ReLU-pool).  save=True (training): also returns the
+    record (pool1 planes + pooling codes) that lets enc_front_bwd skip the recomputation: (yh, yl, saved)."""
     P, cin = x.shape[:2]
     yh = torch.empty(P, 100, 32, dtype=_BF, device=x.device)
     yl = torch.empty_like(yh) if split == 3 else None
+    saved = torch.empty(lib().crw_enc_front_saved_bytes(P), dtype=torch.uint8, device=x.device) if save else None
+    ev = _ev_begin()
     _check(lib().crw_enc_front_fwd(split, _dev(x, "x"), P, cin, _dev(w1.contiguous(), "w1"), _dev(b1, "b1"),
                                    _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"), _bf(yh, "yh"), _bf(yl, "yl"),
-                                   _stream()), "crw_enc_front_fwd")
-    return yh, yl
+                                   ctypes.c_void_p(saved.data_ptr()) if save else None, _stream()), "crw_enc_front_fwd")
+    _ev_end(ev, ("front_fwd", cin, 32))
+    return (yh, yl, saved) if save else (yh, yl)
 
 
 def enc_front_fwd_map(split, x, w1, b1, w2f, b2):
@@ -408,8 +413,8 @@ def enc_front_fwd_map(split, x, w1, b1, w2f, b2):
     return yh, yl
 
 
-def enc_front_bwd(split, x, w1, b1, w2f, b2, w2b, dy):
-    """-> (dw1, db1, dw2, db2)"""
+def enc_front_bwd(split, x, w1, b1, w2f, b2, w2b, dy, saved=None):
+    """-> (dw1, db1, dw2, db2).  saved: the record of enc_front_fwd(save=True) for the same patches (no recomputation)."""
     P, cin = x.shape[:2]
     dev = x.device
     dw1 = torch.empty(8, cin, 5, 5, device=dev)
@@ -418,9 +423,14 @@ def enc_front_bwd(split, x, w1, b1, w2f, b2, w2b, dy):
     db2 = torch.empty(32, device=dev)
     nbytes = lib().crw_enc_front_ws_bytes(P, cin)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if saved is not None and saved.numel() < lib().crw_enc_front_saved_bytes(P):
+        raise RuntimeError("saved record too small for this patch count")
+    ev = _ev_begin()
     _check(lib().crw_enc_front_bwd(split, _dev(x, "x"), P, cin, _dev(w1.contiguous(), "w1"), _dev(b1, "b1"),
                                    _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"), _bf(w2b[0], "w2bh"),
-                                   _bf(w2b[1], "w2bl"), _dev(dy.contiguous(), "dy"), _dev(dw1, "dw1"), _dev(db1, "db1"),
-                                   _dev(dw2, "dw2"), _dev(db2, "db2"), ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()),
-           "crw_enc_front_bwd")
+                                   _bf(w2b[1], "w2bl"), _dev(dy.contiguous(), "dy"),
+                                   ctypes.c_void_p(saved.data_ptr()) if saved is not None else None, _dev(dw1, "dw1"),
+                                   _dev(db1, "db1"), _dev(dw2, "dw2"), _dev(db2, "db2"), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                   _stream()), "crw_enc_front_bwd")
+    _ev_end(ev, ("front_bwd", cin, 32))
     return dw1, db1, dw2, db2

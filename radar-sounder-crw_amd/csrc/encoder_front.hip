@@ -15,6 +15,7 @@
 // fixed order by slice_sum (deterministic).
 #include "crw_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace crw {
 namespace {
@@ -47,6 +48,15 @@ constexpr int KS2 = 7;                     // conv2 k-steps (28 taps, 25 real)
 constexpr int NTH = 1024, NWV = NTH / 64;  // 16 waves per workgroup: the stage is LDS-latency bound, one
                                            // 144 KB workgroup per CU, so latency is hidden by waves, not by workgroups
 
+// What the forward pass keeps per patch for the backward pass when training (crw_enc_front_fwd `saved`), so that the
+// backward kernel does not recompute conv1 -> pool1 -> conv2:
+//   a1 hi / lo planes  [169 pixels][8 ch] bf16 (2704 B each)   the pool1 output = conv2's input (its weight gradient needs it)
+//   k2 codes           [100 outputs][32 ch] 1 byte              pool2: argmax position (2 bits, first maximum in row-major
+//   k1 codes           [169 outputs][8 ch]  1 byte (pad to 1360) order = torch's tie rule) | 4 if the maximum is > 0 (ReLU gate)
+constexpr int SV_A1 = 169 * 16, SV_K2 = 100 * 32, SV_K1 = 1360;
+constexpr int SV_OFF_A1L = SV_A1, SV_OFF_K2 = 2 * SV_A1, SV_OFF_K1 = 2 * SV_A1 + SV_K2, SV_BYTES = 2 * SV_A1 + SV_K2 + SV_K1;  // 9968
+static_assert(SV_BYTES % 16 == 0 && SV_A1 % 16 == 0 && SV_K2 % 16 == 0, "16-byte chunks");
+
 struct FrontArgs {
   const float *x;            // [P][cin][16][16]
   const float *w1, *b1;      // [8][cin][5][5], [8]
@@ -54,6 +64,7 @@ struct FrontArgs {
   const float *b2;           // [32]
   uint16_t *yh, *yl;         // out planes [P][100][32]
   int P, cin;
+  char *saved;               // optional [P][SV_BYTES] (training: see above)
 };
 
 // ---- shared forward pieces ----------------------------------------------------------------------
@@ -99,17 +110,23 @@ __device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
 }
 
 // maxpool 2x2/1 of c1r -> a1 planes (interior of the 15x15 padded image)
+__device__ inline int argmax4(float a, float b, float c, float d);
 template <int SPLIT, bool PAD>
-__device__ inline void pool1(const FwdLds &L, int tid) {
+__device__ inline void pool1(const FwdLds &L, int tid, char *sv = nullptr) {  // sv: this patch's saved record (or null)
   constexpr int ROW = (PAD ? C1W + 2 : C1W) * 8;
   for (int e = tid; e < A1W * A1W * 8; e += NTH) {
     const int c = e & 7, p = e >> 3, y = p / A1W, x = p % A1W;
     const float *s = L.c1r + c1_idx<PAD>(y, x) * 8 + c;
     const float v = fmaxf(fmaxf(s[0], s[8]), fmaxf(s[ROW], s[ROW + 8]));
-    const uint16_t h = f2bf(v);
+    const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
     const int o = ((y + 1) * A1PW + x + 1) * 16 + 2 * c;
     *reinterpret_cast<uint16_t *>(L.a1h + o) = h;
-    if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + o) = f2bf(v - bf2f(h));
+    if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + o) = l;
+    if (sv) {
+      reinterpret_cast<uint16_t *>(sv)[e] = h;
+      if (SPLIT == 3) reinterpret_cast<uint16_t *>(sv + SV_OFF_A1L)[e] = l;
+      sv[SV_OFF_K1 + e] = (char)(argmax4(s[0], s[8], s[ROW], s[ROW + 8]) | (v > 0.f ? 4 : 0));
+    }
   }
 }
 
@@ -206,7 +223,8 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
     lds_barrier();
     conv1_relu<false>(L, a.cin, tid);
     lds_barrier();
-    pool1<SPLIT, false>(L, tid);
+    char *sv = a.saved ? a.saved + (long)pt * SV_BYTES : nullptr;
+    pool1<SPLIT, false>(L, tid, sv);
     lds_barrier();
     conv2_relu<SPLIT, false>(L, b2r, tid);
     lds_barrier();
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
       const uint16_t h = f2bf(v);
       a.yh[(long)pt * ON * 32 + e] = h;
       if (SPLIT == 3) a.yl[(long)pt * ON * 32 + e] = f2bf(v - bf2f(h));
+      if (sv) sv[SV_OFF_K2 + e] = (char)(argmax4(s[0], s[32], s[C2W * 32], s[C2W * 32 + 32]) | (v > 0.f ? 4 : 0));
     }
     // the next iteration's first barrier orders these c2r reads before conv2_relu overwrites it
   }
@@ -702,6 +721,267 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
   }
 }
 
+// ---- backward without recomputation -------------------------------------------------------------------------------
+// The same gradients from what the forward pass saved (pool1 planes + pooling codes, FrontArgs::saved): no conv1 / pool1 /
+// conv2 recomputation (7.5 k of the 29 k cycles per patch of front_bwd_kernel) and the two pooling backward passes read
+// one code byte per window instead of the window's values (8 LDS reads per pixel instead of 13, no comparisons).
+// Phases per patch: registers -> LDS | pool2 backward | conv2 weight gradient + backward-data | pool1 backward | conv1
+// weight gradient.  x, dy and the saved record of the NEXT patch are fetched into registers while this one is processed.
+template <int SPLIT>
+__global__ __launch_bounds__(NTH) void front_bwd_saved_kernel(FrontBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char *p = lds;
+  const int cin = a.f.cin;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
+  float *xs = (float *)take(sizeof(float) * cin * XPW * XPW);
+  char *a1h = take(A1PW * A1PW * 16), *a1l = take(A1PW * A1PW * 16);
+  char *wbh = take(25 * 8 * 32 * 2), *wbl = take(25 * 8 * 32 * 2);
+  char *d2h = take(2 * D2HALF), *d2l = take(2 * D2HALF);
+  float *dyb = (float *)take(sizeof(float) * ON * 32);
+  char *k2s = take(SV_K2), *k1s = take(SV_K1);
+  float *dA1 = dyb, *dC1 = dyb + A1W * A1W * 8;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  for (int e = tid; e < cin * XPW * XPW; e += NTH) xs[e] = 0.f;
+  for (int e = tid; e < A1PW * A1PW * 4; e += NTH) {
+    reinterpret_cast<uint32_t *>(a1h)[e] = 0;
+    reinterpret_cast<uint32_t *>(a1l)[e] = 0;
+  }
+  for (int e = tid; e < 25 * 8 * 32 / 8; e += NTH) {
+    const int ch = e & 3, ci = (e >> 2) & 7, tap = e >> 5;
+    const int d = ((tap * 2 + (ch >> 1)) * 8 + ci) * 2 + (ch & 1);
+    reinterpret_cast<uint4 *>(wbh)[d] = reinterpret_cast<const uint4 *>(a.w2bh)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(wbl)[d] = reinterpret_cast<const uint4 *>(a.w2bl)[e];
+  }
+  for (int e = tid; e < 2 * D2HALF / 4; e += NTH) {
+    reinterpret_cast<uint32_t *>(d2h)[e] = 0;
+    reinterpret_cast<uint32_t *>(d2l)[e] = 0;
+  }
+  __syncthreads();
+
+  f32x4 wacc[2];
+  wacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2 = 0.f, db1 = 0.f, dw1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nout = 8 * cin * 25, nrp = C1W / cin, nrowthr = 8 * cin * 5 * nrp;
+  const uint32_t d2h_a = (uint32_t)(uintptr_t)(lds_cp)d2h, d2l_a = (uint32_t)(uintptr_t)(lds_cp)d2l;
+  const uint32_t a1h_a = (uint32_t)(uintptr_t)(lds_cp)a1h, a1l_a = (uint32_t)(uintptr_t)(lds_cp)a1l;
+  const int p_begin = blockIdx.x * a.patches_per_block;
+  const int p_end = min(a.f.P, p_begin + a.patches_per_block);
+
+  // prefetch registers: dy (one float4), x (one float), and one 16-byte chunk of the saved record per thread:
+  // chunks 0..337 = a1 hi / lo planes, 338..537 = k2 codes, 538..622 = k1 codes
+  constexpr int NA1 = 2 * SV_A1 / 16, NK2 = SV_K2 / 16, NK1 = SV_K1 / 16, NSV = NA1 + NK2 + NK1;
+  static_assert(NSV <= NTH && ON * 32 / 4 <= NTH, "one chunk per thread");
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  float4 dy_r;
+  float x_r = 0.f;
+  u4v sv_r;
+  const __amdgpu_buffer_rsrc_t dy_rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)((long)a.f.P * ON * 32 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.f.x, 0, (int)((long)a.f.P * cin * 256 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sv_rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.f.saved, 0, (int)((long)a.f.P * SV_BYTES), 0x00020000);
+  auto fetch = [&](int pt) {
+    dy_r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dy_rs, tid * 16, pt * (ON * 32 * 4), 0));
+    x_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, tid * 4, pt * (cin * 256 * 4), 0));
+    sv_r = __builtin_amdgcn_raw_buffer_load_b128(sv_rs, min(tid, NSV - 1) * 16, pt * SV_BYTES, 0);
+  };
+  if (p_begin < p_end) fetch(p_begin);
+  for (int pt = p_begin; pt < p_end; ++pt) {
+    // ---- registers -> LDS ----------------------------------------------------------------------
+    if (tid < cin * 256) xs[((tid >> 8) * XPW + ((tid >> 4) & 15) + 1) * XPW + (tid & 15) + 1] = x_r;
+    if (tid < ON * 32 / 4) reinterpret_cast<float4 *>(dyb)[tid] = dy_r;
+    if (tid < NA1) {  // a1 plane chunk: pixel (tid % 169) of plane (tid / 169) -> interior of the padded 15x15 image
+      const int pl = tid / (A1W * A1W), px = tid % (A1W * A1W);
+      *reinterpret_cast<u4v *>((pl ? a1l : a1h) + ((px / A1W + 1) * A1PW + px % A1W + 1) * 16) = sv_r;
+    } else if (tid < NA1 + NK2) {
+      reinterpret_cast<u4v *>(k2s)[tid - NA1] = sv_r;
+    } else if (tid < NSV) {
+      reinterpret_cast<u4v *>(k1s)[tid - NA1 - NK2] = sv_r;
+    }
+    if (pt + 1 < p_end) fetch(pt + 1);
+    lds_barrier();
+
+    // ---- pool2 + ReLU2 backward from the codes: dC2[pix][co] -> padded bf16 planes, bias gradient ------
+    for (int e = tid; e < C2N * 32; e += NTH) {
+      const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
+      float gsum = 0.f;
+#pragma unroll
+      for (int dyw = 0; dyw < 2; ++dyw)
+#pragma unroll
+        for (int dxw = 0; dxw < 2; ++dxw) {
+          const int wy = y - dyw, wx = x - dxw;
+          const bool ok = wy >= 0 && wy < OW && wx >= 0 && wx < OW;
+          const int idx = (min(max(wy, 0), OW - 1) * OW + min(max(wx, 0), OW - 1)) * 32 + co;
+          const int code = k2s[idx];
+          const float d = dyb[idx];
+          gsum += (ok && code == (4 | (dyw * 2 + dxw))) ? d : 0.f;  // this pixel is the window's first maximum and it is > 0
+        }
+      db2 += gsum;
+      const uint16_t h = f2bf(gsum);
+      const int o = (co >> 4) * D2HALF + ((y + 4) * D2PW + x + 4) * 32 + 2 * (co & 15);
+      *reinterpret_cast<uint16_t *>(d2h + o) = h;
+      if (SPLIT == 3) *reinterpret_cast<uint16_t *>(d2l + o) = f2bf(gsum - bf2f(h));
+    }
+    lds_barrier();
+
+    // ---- conv2 weight gradient (as in front_bwd_kernel) ---------------------------------------------
+    {
+      const int t16 = lane & 15, q = t16 >> 2, pq = t16 & 3;
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {
+        const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
+        const bool v_lo = i_lo < C2N, v_hi = i_hi < C2N;
+        const int y_lo = v_lo ? i_lo / C2W : 0, x_lo = v_lo ? i_lo % C2W : 0;
+        const int y_hi = v_hi ? i_hi / C2W : 0, x_hi = v_hi ? i_hi % C2W : 0;
+        const uint32_t ya_lo = (v_lo ? ((y_lo + 4) * D2PW + x_lo + 4) : 0) * 32 + 8 * (pq & 1) + 16 * (pq >> 1);
+        const uint32_t ya_hi = (v_hi ? ((y_hi + 4) * D2PW + x_hi + 4) : 0) * 32 + 8 * (pq & 1) + 16 * (pq >> 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int tile = wave + NWV * u;
+          if (tile < 26) {
+            const int i = tile & 1, nt = tile >> 1;
+            int tap = 2 * nt + (pq >> 1);
+            if (tap > 24) tap = 24;
+            const int toff = (tap / 5) * A1PW + (tap % 5);
+            const uint32_t xa_lo = ((y_lo * A1PW + x_lo) + toff) * 16 + 8 * (pq & 1);
+            const uint32_t xa_hi = ((y_hi * A1PW + x_hi) + toff) * 16 + 8 * (pq & 1);
+            const bf8 ah = tr_pair(d2h_a + ya_lo + D2HALF * i, d2h_a + ya_hi + D2HALF * i);
+            const bf8 bh = tr_pair(a1h_a + xa_lo, a1h_a + xa_hi);
+            bf8 al, bl;
+            if (SPLIT == 3) {
+              al = tr_pair(d2l_a + ya_lo + D2HALF * i, d2l_a + ya_hi + D2HALF * i);
+              bl = tr_pair(a1l_a + xa_lo, a1l_a + xa_hi);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (SPLIT == 3) {
+              wacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[u], 0, 0, 0);
+              wacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[u], 0, 0, 0);
+            }
+            wacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- conv2 backward-data (as in front_bwd_kernel: one image row of dA1 per wave) ---------------------
+    {
+      f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f}, dacc1 = dacc;
+      if (wave < A1W) {
+        const int xl = (r16 >= 4 && r16 < 12) ? r16 - 4 : (r16 < 4 ? 8 + r16 : 12);
+        const int base = (wave + 5) * D2PW + xl + 5;
+        const char *wb = ((SPLIT == 3 && r16 >= 8) ? wbl : wbh) + (g >> 1) * 256 + (r16 & 7) * 32 + (g & 1) * 16;
+        const char *ab = d2h + (g >> 1) * D2HALF + (base - (4 * D2PW + 4)) * 32 + (g & 1) * 16;
+        const long lo_a = d2l - d2h;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+          const int arel = ((4 - tap / 5) * D2PW + (4 - tap % 5)) * 32;
+          const bf8 b = *reinterpret_cast<const bf8 *>(wb + tap * 512);
+          const bf8 ah = *reinterpret_cast<const bf8 *>(ab + arel);
+          if (SPLIT == 3) {
+            const bf8 al = *reinterpret_cast<const bf8 *>(ab + lo_a + arel);
+            dacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, dacc1, 0, 0, 0);
+          }
+          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, dacc, 0, 0, 0);
+        }
+        if (SPLIT == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dacc[r] += __shfl_down(dacc[r], 8, 64) + dacc1[r];
+        }
+      }
+      lds_barrier();  // dyb (aliased by dA1) is no longer read
+      if (wave < A1W && r16 < 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * g + r;
+          const int x = (row >= 4 && row < 12) ? row - 4 : (row < 4 ? 8 + row : 12);
+          if (row < 13) dA1[(wave * A1W + x) * 8 + r16] = dacc[r];
+        }
+    }
+    lds_barrier();
+
+    // ---- pool1 + ReLU1 backward from the codes -> dC1 [8][196] ----------------------------------------
+    for (int e = tid; e < C1N * 8; e += NTH) {
+      const int co = e & 7, pix = e >> 3, y = pix / C1W, x = pix % C1W;
+      float gsum = 0.f;
+#pragma unroll
+      for (int dyw = 0; dyw < 2; ++dyw)
+#pragma unroll
+        for (int dxw = 0; dxw < 2; ++dxw) {
+          const int wy = y - dyw, wx = x - dxw;
+          const bool ok = wy >= 0 && wy < A1W && wx >= 0 && wx < A1W;
+          const int idx = (min(max(wy, 0), A1W - 1) * A1W + min(max(wx, 0), A1W - 1)) * 8 + co;
+          const int code = k1s[idx];
+          const float d = dA1[idx];
+          gsum += (ok && code == (4 | (dyw * 2 + dxw))) ? d : 0.f;
+        }
+      dC1[co * C1N + pix] = gsum;
+      db1 += gsum;
+    }
+    lds_barrier();
+
+    // ---- conv1 weight gradient (as in front_bwd_kernel) ----------------------------------------------
+    if (tid < nrowthr) {
+      const int rp = tid % nrp, q = tid / nrp, ty = q % 5, ci = (q / 5) % cin, co = q / (5 * cin);
+      for (int y = rp; y < C1W; y += nrp) {
+        const float *dr = dC1 + co * C1N + y * C1W, *xr = xs + (ci * XPW + y + ty) * XPW;
+        float dv[C1W], xv[XPW];
+#pragma unroll
+        for (int x = 0; x < C1W; ++x) dv[x] = dr[x];
+#pragma unroll
+        for (int x = 0; x < XPW; ++x) xv[x] = xr[x];
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+          float s1 = 0.f;
+#pragma unroll
+          for (int x = 0; x < C1W; ++x) s1 = fmaf(dv[x], xv[x + tx], s1);
+          dw1[tx] += s1;
+        }
+      }
+    }
+    lds_barrier();
+  }
+
+  // ---- partial sums of this slice -> workspace (layout of front_bwd_kernel) ---------------------------
+  const int PART = 32 * 8 * 25 + 32 + 8 * cin * 25 + 8;
+  float *out = a.part + (long)blockIdx.x * PART;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tile = wave + NWV * u;
+    const int tap = 2 * (tile >> 1) + (r16 >> 3);
+    if (tile < 26 && tap < 25)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[((16 * (tile & 1) + 4 * g + r) * 8 + (r16 & 7)) * 25 + tap] = wacc[u][r];
+  }
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(lds);
+  red[tid] = db2;
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f;
+    for (int k = 0; k < NTH / 32; ++k) s += red[tid + 32 * k];
+    out[32 * 8 * 25 + tid] = s;
+  }
+  __syncthreads();
+  if (tid < nrowthr)
+#pragma unroll
+    for (int tx = 0; tx < 5; ++tx) red[tid * 5 + tx] = dw1[tx];
+  __syncthreads();
+  if (tid < nout) {
+    const int q = tid / 5, tx = tid % 5;
+    float s = 0.f;
+    for (int y = 0; y < nrp; ++y) s += red[(q * nrp + y) * 5 + tx];
+    out[32 * 8 * 25 + 32 + tid] = s;
+  }
+  __syncthreads();
+  red[tid] = db1;
+  __syncthreads();
+  if (tid < 8) {
+    float s = 0.f;
+    for (int k = 0; k < NTH / 8; ++k) s += red[tid + 8 * k];
+    out[32 * 8 * 25 + 32 + nout + tid] = s;
+  }
+}
+
 // out[e] = sum_k part[k * stride + e], e < n: one wave per output, lanes stride the slices, fixed
 // shuffle tree (deterministic)
 // (the four gradient tensors are consecutive segments of a slice's partial vector: one launch covers them all)
@@ -733,6 +1013,10 @@ size_t bwd_lds_bytes(int cin) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
   return fwd_lds_bytes(cin, true) + 2 * r(25 * 8 * 32 * 2) + 2 * r(2 * D2HALF) + r(4 * ON * 32);
 }
+size_t bwd_saved_lds_bytes(int cin) {
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  return r(4 * cin * XPW * XPW) + 2 * r(A1PW * A1PW * 16) + 2 * r(25 * 8 * 32 * 2) + 2 * r(2 * D2HALF) + r(4 * ON * 32) + r(SV_K2) + r(SV_K1);
+}
 int front_slices(int P) { return P < 256 ? P : 256; }  // one 144 KB workgroup per CU
 
 }  // namespace
@@ -757,14 +1041,16 @@ int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint
   return check_launch();
 }
 
+size_t crw_enc_front_saved_bytes(int P) { return P < 1 ? 0 : (size_t)P * SV_BYTES; }
+
 int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
                       const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, uint16_t *y_hi, uint16_t *y_lo,
-                      crw_stream_t stream) {
+                      void *saved, crw_stream_t stream) {
   clear_stale_error();
   if (!x || !w1 || !b1 || !w2_hi || !b2 || !y_hi || P < 1 || (cin != 1 && cin != 2) || (split != 1 && split != 3))
     return CRW_EINVAL;
   if (split == 3 && (!w2_lo || !y_lo)) return CRW_EINVAL;
-  FrontArgs a{x, w1, b1, w2_hi, w2_lo, b2, y_hi, y_lo, P, cin};
+  FrontArgs a{x, w1, b1, w2_hi, w2_lo, b2, y_hi, y_lo, P, cin, static_cast<char *>(saved)};
   const size_t lds = fwd_lds_bytes(cin);
   const int grid = P < 512 ? P : 512;  // two 1024-thread workgroups (60 KB of LDS each) per CU
   if (split == 3) hipLaunchKernelGGL(front_fwd_kernel<3>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
@@ -808,8 +1094,8 @@ size_t crw_enc_front_ws_bytes(int P, int cin) {
 // dy [P][100][32] fp32 -> dw2 [32][8][5][5], db2 [32], dw1 [8][cin][5][5], db1 [8]
 int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
                       const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const uint16_t *w2b_hi,
-                      const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2, void *ws,
-                      size_t ws_bytes, crw_stream_t stream) {
+                      const uint16_t *w2b_lo, const float *dy, const void *saved, float *dw1, float *db1, float *dw2, float *db2,
+                      void *ws, size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
   if (!x || !w1 || !b1 || !w2_hi || !b2 || !w2b_hi || !dy || !dw1 || !db1 || !dw2 || !db2 || !ws || P < 1 ||
       (cin != 1 && cin != 2) || (split != 1 && split != 3))
@@ -818,7 +1104,26 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
   if (ws_bytes < crw_enc_front_ws_bytes(P, cin)) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int nslice = front_slices(P), ppb = (P + nslice - 1) / nslice;
-  FrontBwdArgs a{{x, w1, b1, w2_hi, w2_lo, b2, nullptr, nullptr, P, cin}, w2b_hi, w2b_lo, dy, (float *)ws, ppb, g_front_stamps};
+  FrontBwdArgs a{{x, w1, b1, w2_hi, w2_lo, b2, nullptr, nullptr, P, cin, const_cast<char *>(static_cast<const char *>(saved))},
+                 w2b_hi, w2b_lo, dy, (float *)ws, ppb, g_front_stamps};
+  static const char *force_rc = getenv("CRW_FRONT_RECOMPUTE");  // diagnostics / A-B: ignore the saved record
+  if (saved && !(force_rc && force_rc[0] == '1')) {
+    const size_t ldss = bwd_saved_lds_bytes(cin);
+    static bool sattr3 = false, sattr1 = false;
+    bool &sattr = split == 3 ? sattr3 : sattr1;
+    const void *fn = split == 3 ? (const void *)front_bwd_saved_kernel<3> : (const void *)front_bwd_saved_kernel<1>;
+    if (!sattr) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRW_EHIP;
+      sattr = true;
+    }
+    if (split == 3) hipLaunchKernelGGL(front_bwd_saved_kernel<3>, dim3(nslice), dim3(NTH), ldss, s, a);
+    else hipLaunchKernelGGL(front_bwd_saved_kernel<1>, dim3(nslice), dim3(NTH), ldss, s, a);
+    CRW_TRY(check_launch());
+    const int n2 = 32 * 8 * 25, n1 = 8 * cin * 25, PART = n2 + 32 + n1 + 8;
+    FrontSums fs{(float *)ws, nslice, PART, n2 + 32 + n1 + 8, {n2, n2 + 32, n2 + 32 + n1, n2 + 32 + n1 + 8}, {dw2, db2, dw1, db1}};
+    hipLaunchKernelGGL(front_slice_sum_kernel, dim3((fs.n + 3) / 4), dim3(256), 0, s, fs);
+    return check_launch();
+  }
   const size_t lds = bwd_lds_bytes(cin);
   static bool attr3 = false, attr1 = false;
   if (split == 3) {

@@ -34,7 +34,9 @@ class _HipEncoder(torch.autograd.Function):
         x = x.contiguous()
         w2p = crw_hip.enc_front_pack(w2, split)
         packed = [crw_hip.enc_pack_weights(w, split) for w in (w3, w4, w5)]
-        x3h, x3l = crw_hip.enc_front_fwd(split, x, w1, b1, w2p[:2], b2)
+        # the front end also keeps its pool1 planes and pooling codes (10 KB per patch): its backward kernel then skips the
+        # conv1 -> pool1 -> conv2 recomputation
+        x3h, x3l, fsaved = crw_hip.enc_front_fwd(split, x, w1, b1, w2p[:2], b2, save=True)
         y3h, y3l, _, _ = crw_hip.enc_conv3x3(0, split, x3h, x3l, packed[0][0], packed[0][1], 64, bias=b3)
         y4h, y4l, _, _ = crw_hip.enc_conv3x3(0, split, y3h, y3l, packed[1][0], packed[1][1], 128, bias=b4)
         y5h, _, _, gap = crw_hip.enc_conv3x3(0, split, y4h, y4l, packed[2][0], packed[2][1], 128, bias=b5, gap=True,
@@ -43,7 +45,7 @@ class _HipEncoder(torch.autograd.Function):
         # lo planes are None for plain bf16; everything goes through save_for_backward (in-place weight updates between
         # forward and backward are detected, a second backward without retain_graph raises autograd's own error)
         ctx.save_for_backward(x, w1.detach(), b1.detach(), b2.detach(), *w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h,
-                              *[t for pk in packed for t in (pk[2], pk[3])])
+                              *[t for pk in packed for t in (pk[2], pk[3])], fsaved)
         return gap
 
     @staticmethod
@@ -58,6 +60,7 @@ class _HipEncoder(torch.autograd.Function):
         w2p = sv[4:8]
         x3h, x3l, y3h, y3l, y4h, y4l, y5h = sv[8:15]
         bwd_w = [(sv[15], sv[16]), (sv[17], sv[18]), (sv[19], sv[20])]
+        fsaved = sv[21]
         # dY5 = dgap/100 gated by y5 > 0 (ReLU5 + GAP backward) is built inside the two kernels' loaders
         dgap = dgap.contiguous().float()
         dw5, db5 = crw_hip.enc_wgrad(s, y5h, None, y4h, y4l, dgap=dgap)
@@ -66,7 +69,7 @@ class _HipEncoder(torch.autograd.Function):
         d3h, d3l, _, _ = crw_hip.enc_conv3x3(1, s, d4h, d4l, *bwd_w[1], 64, mask=y3h)    # dY3
         dw3, db3 = crw_hip.enc_wgrad(s, d3h, d3l, x3h, x3l)
         _, _, dx3, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *bwd_w[0], 32, planes=False, f32=True)  # [P,100,32]
-        dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3)
+        dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3, saved=fsaved)
         return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
 class _HipMapTrunk(torch.autograd.Function):

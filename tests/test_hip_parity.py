@@ -568,7 +568,12 @@ def test_encoder_kernels_full_size_by_replication(hip, cin, cout):
             assert torch.equal(v[0], o_s[pl]) and torch.equal(v[reps - 1], o_s[pl])
         dy0 = torch.randn(P0, 100, 32, generator=g).cuda()
         g_s = hip.enc_front_bwd(split, x0, w1, b1, w2p[:2], b2, w2p[2:], dy0)
-        g_f = hip.enc_front_bwd(split, x0.repeat(reps, 1, 1, 1).contiguous(), w1, b1, w2p[:2], b2, w2p[2:], rep(dy0))
+        xr = x0.repeat(reps, 1, 1, 1).contiguous()
+        sv_f = hip.enc_front_fwd(split, xr, w1, b1, w2p[:2], b2, save=True)[2]
+        g_f = hip.enc_front_bwd(split, xr, w1, b1, w2p[:2], b2, w2p[2:], rep(dy0), saved=sv_f)  # the training path's kernel
+        g_r = hip.enc_front_bwd(split, xr, w1, b1, w2p[:2], b2, w2p[2:], rep(dy0))              # recomputing kernel
+        for a_, b_ in zip(g_f, g_r):
+            assert torch.equal(a_, b_)
         for a_, b_ in zip(g_f, g_s):
             torch.testing.assert_close(a_, b_ * reps, rtol=2e-4, atol=2e-4 * (b_.abs().max().item() * reps))
 
@@ -616,9 +621,16 @@ def test_encoder_front_kernels_match_torch(hip, cin, split):
     c = lambda t: t.detach().float().cuda()
     w2f = hip.enc_front_pack(c(w2), split)
     yh, yl = hip.enc_front_fwd(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2))
+    yh2, yl2, saved = hip.enc_front_fwd(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2), save=True)
+    assert torch.equal(yh, yh2) and (yl is None or torch.equal(yl, yl2))
     tol = dict(rtol=1e-4, atol=1e-4) if split == 3 else dict(rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(_planes_value(yh, yl).cpu().double(), _to_planes_ref(y.detach()), **tol)
     dw1, db1, dw2, db2 = hip.enc_front_bwd(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2), w2f[2:], dy.cuda())
+    # the backward from the forward's saved record (pool1 planes + pooling codes, no recomputation): the same arithmetic on
+    # the same values, so the same bits
+    sv = hip.enc_front_bwd(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2), w2f[2:], dy.cuda(), saved=saved)
+    for a_, b_ in zip(sv, (dw1, db1, dw2, db2)):
+        assert torch.equal(a_, b_)
     for got, ref in ((dw2, w2.grad), (db2, b2.grad), (dw1, w1.grad), (db1, b1.grad)):
         # plain bf16: rounding conv2's inputs can flip a max-pool arg-max, which re-routes a gradient
         t = dict(rtol=2e-3, atol=2e-3 * ref.abs().max().item()) if split == 3 else \
