@@ -72,12 +72,27 @@ def seed_labels(seg_ref, N):
     return TF.interpolate(seg_ref[None, None].float(), size=(N, 1), mode='nearest')[0, 0, :, 0]
 
 
-def change_point(xent):
+def column_diffs_async(xent):
+    """|xent[:, i] - xent[:, i+1]| summed over the nodes (src/utils.py:125), copied to pinned host memory WITHOUT
+    blocking: -> (host tensor, event).  Lets the caller queue more GPU work before the host needs the values."""
+    d = (xent[:, :-1] - xent[:, 1:]).abs().sum(0)
+    host = torch.empty(d.shape, dtype=d.dtype, pin_memory=True)
+    host.copy_(d, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev
+
+
+def change_point(xent, diffs=None):
     """PELT(rbf, pen=5) on the column-to-column change of the metric, then `result[-2] + 5` clamped at 0
     (src/utils.py:125-132).  Uses `ruptures` when it is importable, else the restatement of its published
     algorithm in pelt.py (parity unpinned, see there); like the reference, any failure -- e.g. fewer than
-    two breakpoints -- yields None."""
-    diffs = (xent[:, :-1] - xent[:, 1:]).abs().sum(0).cpu().numpy()
+    two breakpoints -- yields None.  diffs: the (host, event) pair of `column_diffs_async` if already requested."""
+    if diffs is not None:
+        diffs[1].synchronize()
+        diffs = diffs[0].numpy()
+    else:
+        diffs = (xent[:, :-1] - xent[:, 1:]).abs().sum(0).cpu().numpy()
     try:
         try:
             import ruptures as rpt
@@ -106,7 +121,7 @@ def propagate(seq, seg_ref, model, lp, nclasses, do_pos_embed, use_last):
     if T == 1:  # a one-frame item (the correction step of test_all.py can ask for it): nothing to propagate, like the reference
         return seed[:, None].clone(), torch.zeros(N, 0), None
     xent = crw_hip.xent_metric(feats)
-    change_idx = change_point(xent)
+    diffs = column_diffs_async(xent) if T > 2 else None  # on its way to the host before the label propagation is queued
     if hasattr(lp, 'propagate_all'):
         pred, _ = lp.propagate_all(feats, seed, nclasses)
     else:  # foreign label-propagation object: reference's frame-by-frame protocol
@@ -120,6 +135,8 @@ def propagate(seq, seg_ref, model, lp, nclasses, do_pos_embed, use_last):
             fl.append(as_feat(n))
             ml.append(mask)
             pred[:, n] = mask.argmax(1).squeeze()
+    # the change point is host work (PELT on T-2 samples): it runs while the GPU propagates the labels queued above
+    change_idx = change_point(xent, diffs)
     return pred, xent.cpu(), change_idx
 
 

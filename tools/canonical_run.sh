@@ -3,7 +3,7 @@
 # rocprofv3 kernel summary of the default bench command.  Run on the GPU box from the repo root:
 #   bash tools/canonical_run.sh            (outputs under gpurun_out/canon/)
 set -o pipefail
-O=gpurun_out/canon
+O=gpurun_out/${1:-canon}
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $O/status.txt
 tail -2 $O/pytest_gpu.log
