@@ -203,6 +203,14 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
                       const uint16_t *w2b_lo, const float *dy, const void *saved, float *dw1, float *db1, float *dw2,
                       float *db2, void *ws, size_t ws_bytes, crw_stream_t stream);
 
+/* The same backward on patches of any size h, w >= 7 (training at patch sizes other than 16x16): x [P][cin][H][W], dy
+ * [P][H-6][W-6][32] fp32 = gradient of the planes of crw_enc_front_fwd_map.  Unit of work = (patch, 10x10 tile of that map);
+ * ws: crw_enc_front_ws_bytes(P * ceil((H-6)/10) * ceil((W-6)/10), cin). */
+int crw_enc_front_bwd_map(int split, const float *x, int P, int cin, int H, int W, const float *w1, const float *b1,
+                          const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const uint16_t *w2b_hi,
+                          const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2,
+                          void *ws, size_t ws_bytes, crw_stream_t stream);
+
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous
  * call, e.g. when timing the GEMM alone).  split = 1: plain bf16 operands; split = 3: hi/lo operand

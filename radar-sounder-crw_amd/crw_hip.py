@@ -55,6 +55,8 @@ SIGNATURES = {
     "crw_enc_front_ws_bytes": (_c_sz, [_c_int, _c_int]),
     "crw_enc_front_bwd": (_c_int, [_c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _c_sz, _p]),
+    "crw_enc_front_bwd_map": (_c_int, [_c_int, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                       _c_sz, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -433,4 +435,23 @@ def enc_front_bwd(split, x, w1, b1, w2f, b2, w2b, dy, saved=None):
                                    _dev(db1, "db1"), _dev(dw2, "dw2"), _dev(db2, "db2"), ctypes.c_void_p(ws.data_ptr()), nbytes,
                                    _stream()), "crw_enc_front_bwd")
     _ev_end(ev, ("front_bwd", cin, 32))
+    return dw1, db1, dw2, db2
+
+
+def enc_front_bwd_map(split, x, w1, b1, w2f, b2, w2b, dy):
+    """front-end backward on patches of any size: x [P,cin,H,W], dy [P,(H-6)*(W-6),32] fp32 -> (dw1, db1, dw2, db2)."""
+    P, cin, H, W = x.shape
+    dev = x.device
+    dw1 = torch.empty(8, cin, 5, 5, device=dev)
+    db1 = torch.empty(8, device=dev)
+    dw2 = torch.empty(32, 8, 5, 5, device=dev)
+    db2 = torch.empty(32, device=dev)
+    units = P * ((H - 6 + 9) // 10) * ((W - 6 + 9) // 10)
+    nbytes = lib().crw_enc_front_ws_bytes(units, cin)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _check(lib().crw_enc_front_bwd_map(split, _dev(x.contiguous(), "x"), P, cin, H, W, _dev(w1.contiguous(), "w1"), _dev(b1, "b1"),
+                                       _bf(w2f[0], "w2h"), _bf(w2f[1], "w2l"), _dev(b2, "b2"), _bf(w2b[0], "w2bh"),
+                                       _bf(w2b[1], "w2bl"), _dev(dy.contiguous(), "dy"), _dev(dw1, "dw1"), _dev(db1, "db1"),
+                                       _dev(dw2, "dw2"), _dev(db2, "db2"), ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()),
+           "crw_enc_front_bwd_map")
     return dw1, db1, dw2, db2

@@ -373,6 +373,9 @@ struct FrontBwdArgs {
   float *part;               // [nslice][PART] partial sums: dW2 [32][8][25], db2 [32], dW1 [8][cin][25], db1 [8]
   int patches_per_block;
   long long *stamps;         // `make STAMPS=1` builds: [grid][NPHASE] cycles per phase summed over the slice (else null)
+  // tiled variant only (front_bwd_tile_kernel): patches are [P][cin][H][W], dy is the map [P][H-6][W-6][32], the unit of
+  // work is (patch, 10x10 tile of that map) and `patches_per_block` counts units
+  int H, W, tiles_x, tiles_y;
 };
 [[maybe_unused]] constexpr int NPHASE = 10;
 #ifdef CRW_CONV_STAMPS
@@ -706,6 +709,291 @@ __global__ __launch_bounds__(NTH) void front_bwd_kernel(FrontBwdArgs a) {
     for (int tx = 0; tx < 5; ++tx) red[tid * 5 + tx] = dw1[tx];  // [(co, ci, ty)][row part][tx]
   __syncthreads();
   if (tid < nout) {  // output o = ((co * cin + ci) * 5 + ty) * 5 + tx: add its row parts in a fixed order
+    const int q = tid / 5, tx = tid % 5;
+    float s = 0.f;
+    for (int y = 0; y < nrp; ++y) s += red[(q * nrp + y) * 5 + tx];
+    out[32 * 8 * 25 + 32 + tid] = s;
+  }
+  __syncthreads();
+  red[tid] = db1;
+  __syncthreads();
+  if (tid < 8) {
+    float s = 0.f;
+    for (int k = 0; k < NTH / 8; ++k) s += red[tid + 8 * k];
+    out[32 * 8 * 25 + 32 + nout + tid] = s;
+  }
+}
+
+// ---- backward on patches of any size (training at patch sizes other than 16x16) -----------------------------------------
+// The unit of work is (patch, 10x10 tile of the pool2 output map), with the geometry of front_fwd_map_kernel: a 20x20 window
+// of the patch (zeros outside it), conv1 over 16x16 positions, the 15x15 a1 window conv2 needs (a position outside the a1 map
+// holds conv2's zero padding and passes no gradient), conv2 11x11, pool2 10x10.  Every gradient is linear in dy and every
+// pooled output belongs to exactly one tile, so the per-tile contributions to dW1 / dW2 / db simply add up (overlapping
+// windows recompute the same forward values, hence the same ReLU gates and arg-max choices).  The phases are those of
+// front_bwd_kernel -- whose 16x16 patch is the one-tile case with the window's border ring outside the maps -- with the
+// extents 16 / 15 instead of 14 / 13; conv2, pool2 backward and the conv2 weight gradient are shared code.
+constexpr int TXW = MXW, TCW = MC1W, TCN = TCW * TCW, TAW = A1PW;  // 20, 16, 256, 15
+
+template <int SPLIT>
+__global__ __launch_bounds__(NTH) void front_bwd_tile_kernel(FrontBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char *p = lds;
+  const int cin = a.f.cin;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 15) & ~(size_t)15; return r; };
+  FwdLds L;
+  L.xs = (float *)take(sizeof(float) * cin * TXW * TXW);
+  L.w1 = (float *)take(sizeof(float) * (8 * cin * 25 + 8));
+  L.c1r = (float *)take(sizeof(float) * (TCW + 2) * (TCW + 2) * 8);  // bordered: pool_bwd_pixel reads 3x3 neighbourhoods
+  L.a1h = take(TAW * TAW * 16);
+  L.a1l = take(TAW * TAW * 16);
+  L.w2h = take(KS2 * 32 * 32 * 2);
+  L.w2l = take(KS2 * 32 * 32 * 2);
+  L.c2r = (float *)take(sizeof(float) * (C2W + 2) * (C2W + 2) * 32);
+  char *wbh = take(25 * 8 * 32 * 2), *wbl = take(25 * 8 * 32 * 2);
+  char *d2h = take(2 * D2HALF), *d2l = take(2 * D2HALF);
+  float *dyb = (float *)take(sizeof(float) * ON * 32);
+  // dA1 [225][8] aliases dyb and dC1 [8][256] aliases c2r: both are dead after the pool2 backward phase (157 KB of LDS in all)
+  float *dA1 = dyb, *dC1 = L.c2r;
+  static_assert(TAW * TAW * 8 <= ON * 32 && TCN * 8 <= (C2W + 2) * (C2W + 2) * 32, "aliases");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  for (int e = tid; e < 8 * cin * 25; e += NTH) {  // [co][ci][tap] -> [ci][tap][co]
+    const int t = e % 25, ci = (e / 25) % cin, co = e / (25 * cin);
+    L.w1[(ci * 25 + t) * 8 + co] = a.f.w1[e];
+  }
+  if (tid < 8) L.w1[8 * cin * 25 + tid] = a.f.b1[tid];
+  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
+    const int d = w2_lds_chunk(e);
+    reinterpret_cast<uint4 *>(L.w2h)[d] = reinterpret_cast<const uint4 *>(a.f.w2h)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[d] = reinterpret_cast<const uint4 *>(a.f.w2l)[e];
+  }
+  for (int e = tid; e < 25 * 8 * 32 / 8; e += NTH) {
+    const int ch = e & 3, ci = (e >> 2) & 7, tap = e >> 5;
+    const int d = ((tap * 2 + (ch >> 1)) * 8 + ci) * 2 + (ch & 1);
+    reinterpret_cast<uint4 *>(wbh)[d] = reinterpret_cast<const uint4 *>(a.w2bh)[e];
+    if (SPLIT == 3) reinterpret_cast<uint4 *>(wbl)[d] = reinterpret_cast<const uint4 *>(a.w2bl)[e];
+  }
+  for (int e = tid; e < 2 * D2HALF / 4; e += NTH) {
+    reinterpret_cast<uint32_t *>(d2h)[e] = 0;
+    reinterpret_cast<uint32_t *>(d2l)[e] = 0;
+  }
+  __syncthreads();
+
+  f32x4 wacc[2];
+  wacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2 = 0.f, db1 = 0.f, dw1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nout = 8 * cin * 25, nrp = TCW / cin, nrowthr = 8 * cin * 5 * nrp;  // 640 threads either way
+  const uint32_t d2h_a = (uint32_t)(uintptr_t)(lds_cp)d2h, d2l_a = (uint32_t)(uintptr_t)(lds_cp)d2l;
+  const uint32_t a1h_a = (uint32_t)(uintptr_t)(lds_cp)L.a1h, a1l_a = (uint32_t)(uintptr_t)(lds_cp)L.a1l;
+  const int H = a.H, W = a.W, Ho = H - 6, Wo = W - 6, ntile = a.tiles_x * a.tiles_y;
+  const int u_begin = blockIdx.x * a.patches_per_block;
+  const int u_end = min(a.f.P * ntile, u_begin + a.patches_per_block);
+  const float b2r = a.f.b2[16 * (wave & 1) + r16];
+
+  for (int u = u_begin; u < u_end; ++u) {
+    const int pt = u / ntile, tile = u % ntile;
+    const int oy0 = (tile / a.tiles_x) * OW, ox0 = (tile % a.tiles_x) * OW;
+    // ---- window of the patch and the tile of dy (zeros outside the patch / the map) ---------------------------
+    for (int e = tid; e < cin * TXW * TXW; e += NTH) {
+      const int ci = e / (TXW * TXW), r = (e / TXW) % TXW, c = e % TXW;
+      const int iy = oy0 + r - 2, ix = ox0 + c - 2;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float v = a.f.x[(((long)pt * cin + ci) * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+      L.xs[e] = ok ? v : 0.f;
+    }
+    for (int e = tid; e < ON * 32 / 4; e += NTH) {
+      const int q = e >> 3, c4 = e & 7, y = q / OW, x = q % OW;
+      const bool ok = oy0 + y < Ho && ox0 + x < Wo;
+      const float4 v = *reinterpret_cast<const float4 *>(a.dy + (((long)pt * Ho + min(oy0 + y, Ho - 1)) * Wo + min(ox0 + x, Wo - 1)) * 32 + 4 * c4);
+      reinterpret_cast<float4 *>(dyb)[e] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    lds_barrier();
+    // ---- recompute the forward of this tile -------------------------------------------------------------------
+    if (tid < TCN * 2) {  // conv1 + bias + ReLU over the 16x16 positions: thread = (position, 4 of 8 channels)
+      const int pix = tid >> 1, c0 = 4 * (tid & 1);
+      const int y = pix / TCW, xx = pix % TCW;
+      float4 acc = *reinterpret_cast<const float4 *>(L.w1 + 8 * cin * 25 + c0);
+      for (int ci = 0; ci < cin; ++ci) {
+        const float *xs = L.xs + (ci * TXW + y) * TXW + xx;
+        const float *w = L.w1 + ci * 25 * 8 + c0;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+          const float v = xs[(t / 5) * TXW + t % 5];
+          const float4 wv = *reinterpret_cast<const float4 *>(w + t * 8);
+          acc.x = fmaf(v, wv.x, acc.x);
+          acc.y = fmaf(v, wv.y, acc.y);
+          acc.z = fmaf(v, wv.z, acc.z);
+          acc.w = fmaf(v, wv.w, acc.w);
+        }
+      }
+      *reinterpret_cast<float4 *>(L.c1r + ((y + 1) * (TCW + 2) + xx + 1) * 8 + c0) =
+          float4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+    }
+    lds_barrier();
+    // pool1 over the whole 15x15 a1 window: local (r, c) = a1 map (oy0 + r - 1, ox0 + c - 1); outside the map = conv2's zero padding
+    for (int e = tid; e < TAW * TAW * 8; e += NTH) {
+      const int c = e & 7, q = e >> 3, r = q / TAW, cc = q % TAW;
+      const int ay = oy0 + r - 1, ax = ox0 + cc - 1;
+      float v = 0.f;
+      if (ay >= 0 && ay < H - 3 && ax >= 0 && ax < W - 3) {
+        const float *s1 = L.c1r + ((r + 1) * (TCW + 2) + cc + 1) * 8 + c;
+        v = fmaxf(fmaxf(s1[0], s1[8]), fmaxf(s1[(TCW + 2) * 8], s1[(TCW + 2) * 8 + 8]));
+      }
+      const uint16_t h = f2bf(v);
+      *reinterpret_cast<uint16_t *>(L.a1h + q * 16 + 2 * c) = h;
+      if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + q * 16 + 2 * c) = f2bf(v - bf2f(h));
+    }
+    lds_barrier();
+    conv2_relu<SPLIT, true>(L, b2r, tid);
+    lds_barrier();
+
+    // ---- pool2 + ReLU2 backward (as in front_bwd_kernel) ------------------------------------------------------
+    for (int e = tid; e < C2N * 32; e += NTH) {
+      const int co = e & 31, pix = e >> 5, y = pix / C2W, x = pix % C2W;
+      const float gsum = pool_bwd_pixel<C2W, 32>(L.c2r, dyb, y, x, co);
+      db2 += gsum;
+      const uint16_t h = f2bf(gsum);
+      const int o = (co >> 4) * D2HALF + ((y + 4) * D2PW + x + 4) * 32 + 2 * (co & 15);
+      *reinterpret_cast<uint16_t *>(d2h + o) = h;
+      if (SPLIT == 3) *reinterpret_cast<uint16_t *>(d2l + o) = f2bf(gsum - bf2f(h));
+    }
+    lds_barrier();
+
+    // ---- conv2 weight gradient (as in front_bwd_kernel) -------------------------------------------------------
+    {
+      const int t16 = lane & 15, q = t16 >> 2, pq = t16 & 3;
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {
+        const int i_lo = 32 * ks + 8 * g + q, i_hi = i_lo + 4;
+        const bool v_lo = i_lo < C2N, v_hi = i_hi < C2N;
+        const int y_lo = v_lo ? i_lo / C2W : 0, x_lo = v_lo ? i_lo % C2W : 0;
+        const int y_hi = v_hi ? i_hi / C2W : 0, x_hi = v_hi ? i_hi % C2W : 0;
+        const uint32_t ya_lo = (v_lo ? ((y_lo + 4) * D2PW + x_lo + 4) : 0) * 32 + 8 * (pq & 1) + 16 * (pq >> 1);
+        const uint32_t ya_hi = (v_hi ? ((y_hi + 4) * D2PW + x_hi + 4) : 0) * 32 + 8 * (pq & 1) + 16 * (pq >> 1);
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          const int tl = wave + NWV * uu;
+          if (tl < 26) {
+            const int i = tl & 1, nt = tl >> 1;
+            int tap = 2 * nt + (pq >> 1);
+            if (tap > 24) tap = 24;
+            const int toff = (tap / 5) * A1PW + (tap % 5);
+            const uint32_t xa_lo = ((y_lo * A1PW + x_lo) + toff) * 16 + 8 * (pq & 1);
+            const uint32_t xa_hi = ((y_hi * A1PW + x_hi) + toff) * 16 + 8 * (pq & 1);
+            const bf8 ah = tr_pair(d2h_a + ya_lo + D2HALF * i, d2h_a + ya_hi + D2HALF * i);
+            const bf8 bh = tr_pair(a1h_a + xa_lo, a1h_a + xa_hi);
+            bf8 al, bl;
+            if (SPLIT == 3) {
+              al = tr_pair(d2l_a + ya_lo + D2HALF * i, d2l_a + ya_hi + D2HALF * i);
+              bl = tr_pair(a1l_a + xa_lo, a1l_a + xa_hi);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (SPLIT == 3) {
+              wacc[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[uu], 0, 0, 0);
+              wacc[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[uu], 0, 0, 0);
+            }
+            wacc[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[uu], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- conv2 backward-data: one row of the 15x15 a1 window per wave (15 waves), masked where the window leaves the a1 map ----
+    {
+      f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f}, dacc1 = dacc;
+      if (wave < TAW) {
+        const int xl = (r16 >= 4 && r16 < 12) ? r16 - 4 : (r16 < 4 ? 8 + r16 : min(r16, TAW - 1));
+        const int base = (wave + 4) * D2PW + xl + 4;  // a1 window position (wave, xl) = padded dC2 pixel of tap (0,0)
+        const char *wb = ((SPLIT == 3 && r16 >= 8) ? wbl : wbh) + (g >> 1) * 256 + (r16 & 7) * 32 + (g & 1) * 16;
+        const char *ab = d2h + (g >> 1) * D2HALF + (base - (4 * D2PW + 4)) * 32 + (g & 1) * 16;
+        const long lo_a = d2l - d2h;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+          const int arel = ((4 - tap / 5) * D2PW + (4 - tap % 5)) * 32;
+          const bf8 b = *reinterpret_cast<const bf8 *>(wb + tap * 512);
+          const bf8 ah = *reinterpret_cast<const bf8 *>(ab + arel);
+          if (SPLIT == 3) {
+            const bf8 al = *reinterpret_cast<const bf8 *>(ab + lo_a + arel);
+            dacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, dacc1, 0, 0, 0);
+          }
+          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, dacc, 0, 0, 0);
+        }
+        if (SPLIT == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dacc[r] += __shfl_down(dacc[r], 8, 64) + dacc1[r];
+        }
+        if (r16 < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            const int x = (row >= 4 && row < 12) ? row - 4 : (row < 4 ? 8 + row : min(row, TAW - 1));
+            const int ay = oy0 + wave - 1, ax = ox0 + x - 1;
+            const bool ok = ay >= 0 && ay < H - 3 && ax >= 0 && ax < W - 3;
+            if (row < TAW) dA1[(wave * TAW + x) * 8 + r16] = ok ? dacc[r] : 0.f;
+          }
+        }
+      }
+    }
+    lds_barrier();
+
+    // ---- pool1 + ReLU1 backward -> dC1 [8][256] ---------------------------------------------------------------
+    for (int e = tid; e < TCN * 8; e += NTH) {
+      const int co = e & 7, pix = e >> 3, y = pix / TCW, x = pix % TCW;
+      const float gsum = pool_bwd_pixel<TCW, 8>(L.c1r, dA1, y, x, co);
+      dC1[co * TCN + pix] = gsum;
+      db1 += gsum;
+    }
+    lds_barrier();
+
+    // ---- conv1 weight gradient: thread = (co, ci, tap row ty, pixel-row part) ----------------------------------
+    if (tid < nrowthr) {
+      const int rp = tid % nrp, q = tid / nrp, ty = q % 5, ci = (q / 5) % cin, co = q / (5 * cin);
+      for (int y = rp; y < TCW; y += nrp) {
+        const float *dr = dC1 + co * TCN + y * TCW, *xr = L.xs + (ci * TXW + y + ty) * TXW;
+        float dv[TCW], xv[TXW];
+#pragma unroll
+        for (int x = 0; x < TCW; ++x) dv[x] = dr[x];
+#pragma unroll
+        for (int x = 0; x < TXW; ++x) xv[x] = xr[x];
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+          float s1 = 0.f;
+#pragma unroll
+          for (int x = 0; x < TCW; ++x) s1 = fmaf(dv[x], xv[x + tx], s1);
+          dw1[tx] += s1;
+        }
+      }
+    }
+    lds_barrier();  // the next unit overwrites xs / dyb
+  }
+
+  // ---- partial sums of this slice -> workspace (layout of front_bwd_kernel) ---------------------------
+  const int PART = 32 * 8 * 25 + 32 + 8 * cin * 25 + 8;
+  float *out = a.part + (long)blockIdx.x * PART;
+#pragma unroll
+  for (int uu = 0; uu < 2; ++uu) {
+    const int tl = wave + NWV * uu;
+    const int tap = 2 * (tl >> 1) + (r16 >> 3);
+    if (tl < 26 && tap < 25)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[((16 * (tl & 1) + 4 * g + r) * 8 + (r16 & 7)) * 25 + tap] = wacc[uu][r];
+  }
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(lds);
+  red[tid] = db2;
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f;
+    for (int k = 0; k < NTH / 32; ++k) s += red[tid + 32 * k];
+    out[32 * 8 * 25 + tid] = s;
+  }
+  __syncthreads();
+  if (tid < nrowthr)
+#pragma unroll
+    for (int tx = 0; tx < 5; ++tx) red[tid * 5 + tx] = dw1[tx];
+  __syncthreads();
+  if (tid < nout) {
     const int q = tid / 5, tx = tid % 5;
     float s = 0.f;
     for (int y = 0; y < nrp; ++y) s += red[(q * nrp + y) * 5 + tx];
@@ -1146,6 +1434,48 @@ int crw_enc_front_bwd(int split, const float *x, int P, int cin, const float *w1
   // the partial layout is [dW2 | db2 | dW1 | db1]; the outputs are four separate tensors
   float *part = (float *)ws;
   FrontSums fs{part, nslice, PART, n2 + 32 + n1 + 8, {n2, n2 + 32, n2 + 32 + n1, n2 + 32 + n1 + 8}, {dw2, db2, dw1, db1}};
+  hipLaunchKernelGGL(front_slice_sum_kernel, dim3((fs.n + 3) / 4), dim3(256), 0, s, fs);
+  return check_launch();
+}
+
+
+/* backward of the front end on patches of any size (h, w >= 7): x [P][cin][H][W], dy [P][H-6][W-6][32] fp32 (gradient of the
+ * planes crw_enc_front_fwd_map produces) -> dw1, db1, dw2, db2.  ws: crw_enc_front_ws_bytes(P * tiles, cin). */
+int crw_enc_front_bwd_map(int split, const float *x, int P, int cin, int H, int W, const float *w1, const float *b1,
+                          const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const uint16_t *w2b_hi,
+                          const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2, void *ws,
+                          size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !w1 || !b1 || !w2_hi || !b2 || !w2b_hi || !dy || !dw1 || !db1 || !dw2 || !db2 || !ws || P < 1 ||
+      (cin != 1 && cin != 2) || (split != 1 && split != 3) || H < 7 || W < 7)
+    return CRW_EINVAL;
+  if (split == 3 && (!w2_lo || !w2b_lo)) return CRW_EINVAL;
+  const int tx = (W - 6 + OW - 1) / OW, ty = (H - 6 + OW - 1) / OW;
+  const long units_l = (long)P * tx * ty;
+  if (units_l > 0x7fffffffL) return CRW_EINVAL;
+  const int units = (int)units_l;
+  if (ws_bytes < crw_enc_front_ws_bytes(units, cin)) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int nslice = front_slices(units);
+  const int upb = (units + nslice - 1) / nslice;
+  nslice = (units + upb - 1) / upb;
+  FrontBwdArgs a{{x, w1, b1, w2_hi, w2_lo, b2, nullptr, nullptr, P, cin, nullptr}, w2b_hi, w2b_lo, dy, (float *)ws, upb, nullptr, H, W, tx, ty};
+  const void *fn = split == 3 ? (const void *)front_bwd_tile_kernel<3> : (const void *)front_bwd_tile_kernel<1>;
+  static bool attr3 = false, attr1 = false;
+  bool &attr = split == 3 ? attr3 : attr1;
+  if (!attr) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRW_EHIP;
+    attr = true;
+  }
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const size_t lds = r(4 * cin * TXW * TXW) + r(4 * (8 * cin * 25 + 8)) + r(4 * (TCW + 2) * (TCW + 2) * 8) + 2 * r(TAW * TAW * 16) +
+                     2 * r(KS2 * 32 * 32 * 2) + r(4 * (C2W + 2) * (C2W + 2) * 32) + 2 * r(25 * 8 * 32 * 2) + 2 * r(2 * D2HALF) +
+                     r(4 * ON * 32);
+  if (split == 3) hipLaunchKernelGGL(front_bwd_tile_kernel<3>, dim3(nslice), dim3(NTH), lds, s, a);
+  else hipLaunchKernelGGL(front_bwd_tile_kernel<1>, dim3(nslice), dim3(NTH), lds, s, a);
+  CRW_TRY(check_launch());
+  const int n2 = 32 * 8 * 25, n1 = 8 * cin * 25, PART = n2 + 32 + n1 + 8;
+  FrontSums fs{(float *)ws, nslice, PART, n2 + 32 + n1 + 8, {n2, n2 + 32, n2 + 32 + n1, n2 + 32 + n1 + 8}, {dw2, db2, dw1, db1}};
   hipLaunchKernelGGL(front_slice_sum_kernel, dim3((fs.n + 3) / 4), dim3(256), 0, s, fs);
   return check_launch();
 }

@@ -10,8 +10,8 @@ HIP kernels (``CNN.hip_convs``: "bf16x3" = hi/lo bf16 operand pairs on the matri
 results, the default; "bf16" = plain bf16 operands; None = PyTorch-ROCm ops).  Only the linear
 head stays a PyTorch op.  At other patch sizes the 3x3 trunk runs on the tiled variants of the same kernels (10x10 output
 tiles over the feature map): inference (``torch.no_grad``) the whole trunk incl. the front end (``_hip_inference_trunk``);
-training conv3-5 + pooling forward, backward-data and weight gradients (``_HipMapTrunk``), with the small front end on
-PyTorch-ROCm ops.  CPU tensors and ``Resnet`` use PyTorch ops (a CUDA batch that misses the HIP path warns once).
+training likewise, forward and backward (``_HipMapEncoder``).  CPU tensors and ``Resnet`` use PyTorch ops (a CUDA batch that
+misses the HIP path warns once).
 """
 import warnings
 
@@ -72,45 +72,52 @@ class _HipEncoder(torch.autograd.Function):
         dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3, saved=fsaved)
         return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
-class _HipMapTrunk(torch.autograd.Function):
-    """conv3 / conv4 / conv5 (+ReLU) and the global average pool on feature maps of ANY size (training at patch sizes other
-    than 16x16, e.g. the 32x32 patches of BASELINE config 5): forward, backward-data and weight gradients all on the tiled
-    HIP kernels (10x10 output tiles over the map: `crw_enc_conv3x3_map`, `crw_enc_conv3x3_wgrad_map`, `crw_enc_gap_bwd`).
-    a2 [P,32,H,W] fp32 (output of the front end) -> pooled features [P,128]; the gradient with respect to a2 is returned, so
-    the front end (conv1 / pool / conv2 / pool, 3 % of the encoder's flops) trains through PyTorch autograd at these sizes."""
+class _HipMapEncoder(torch.autograd.Function):
+    """The whole conv trunk of ``CNN`` on patches of ANY size (training at patch sizes other than 16x16, e.g. the 32x32
+    patches of BASELINE config 5), forward and backward on the tiled HIP kernels (10x10 output tiles over the feature map):
+    front end `crw_enc_front_fwd_map` / `crw_enc_front_bwd_map`, conv3-5 `crw_enc_conv3x3_map` (mode 0 forward, mode 1
+    backward-data) / `crw_enc_conv3x3_wgrad_map`, ReLU + average-pool backward `crw_enc_gap_bwd`.
+    x [P,cin,h,w] fp32 -> pooled features [P,128]."""
 
     @staticmethod
-    def forward(ctx, a2, w3, b3, w4, b4, w5, b5, split):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, split):
         import crw_hip
-        P, _, H, W = a2.shape
-        packed = [crw_hip.enc_pack_weights(w, split) for w in (w3, w4, w5)]
-        x3h, x3l = crw_hip.enc_pack_input_map(a2.contiguous(), split)
+        x = x.contiguous()
+        P, _, h, w = x.shape
+        H, W = h - 6, w - 6
+        w2p = crw_hip.enc_front_pack(w2, split)
+        packed = [crw_hip.enc_pack_weights(wt, split) for wt in (w3, w4, w5)]
+        x3h, x3l = crw_hip.enc_front_fwd_map(split, x, w1, b1, w2p[:2], b2)
         y3h, y3l, _ = crw_hip.enc_conv3x3_map(split, x3h, x3l, packed[0][0], packed[0][1], 64, H, W, bias=b3)
         y4h, y4l, _ = crw_hip.enc_conv3x3_map(split, y3h, y3l, packed[1][0], packed[1][1], 128, H, W, bias=b4)
         y5h, _, gap = crw_hip.enc_conv3x3_map(split, y4h, y4l, packed[2][0], packed[2][1], 128, H, W, bias=b5, gap=True,
                                               lo_plane=False)  # only the sign of y5 is needed later
         ctx.split, ctx.hw = split, (H, W)
-        ctx.save_for_backward(x3h, x3l, y3h, y3l, y4h, y4l, y5h, *[t for pk in packed for t in (pk[2], pk[3])])
+        ctx.save_for_backward(x, w1.detach(), b1.detach(), b2.detach(), *w2p, x3h, x3l, y3h, y3l, y4h, y4l, y5h,
+                              *[t for pk in packed for t in (pk[2], pk[3])])
         return gap
 
     @staticmethod
     def backward(ctx, dgap):
         import crw_hip
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("the fused HIP encoder does not produce a gradient for its input patches (the reference never "
+                               "asks for one); set CNN.hip_convs = None to differentiate with respect to the input")
         s, (H, W) = ctx.split, ctx.hw
         sv = ctx.saved_tensors
-        x3h, x3l, y3h, y3l, y4h, y4l, y5h = sv[:7]
-        bw = [(sv[7], sv[8]), (sv[9], sv[10]), (sv[11], sv[12])]
+        x, w1, b1, b2 = sv[:4]
+        w2p = sv[4:8]
+        x3h, x3l, y3h, y3l, y4h, y4l, y5h = sv[8:15]
+        bw = [(sv[15], sv[16]), (sv[17], sv[18]), (sv[19], sv[20])]
         d5h, d5l = crw_hip.enc_gap_bwd(dgap.contiguous().float(), y5h, s)               # ReLU5 + GAP backward
         dw5, db5 = crw_hip.enc_wgrad_map(s, d5h, d5l, y4h, y4l, H, W)
         d4h, d4l, _ = crw_hip.enc_conv3x3_map(s, d5h, d5l, *bw[2], 128, H, W, mode=1, mask=y4h)
         dw4, db4 = crw_hip.enc_wgrad_map(s, d4h, d4l, y3h, y3l, H, W)
         d3h, d3l, _ = crw_hip.enc_conv3x3_map(s, d4h, d4l, *bw[1], 64, H, W, mode=1, mask=y3h)
         dw3, db3 = crw_hip.enc_wgrad_map(s, d3h, d3l, x3h, x3l, H, W)
-        da2 = None
-        if ctx.needs_input_grad[0]:
-            _, _, dx3 = crw_hip.enc_conv3x3_map(s, d3h, d3l, *bw[0], 32, H, W, mode=1, planes=False, f32=True)  # [P, H*W, 32]
-            da2 = dx3.view(-1, H, W, 32).permute(0, 3, 1, 2)
-        return da2, dw3, db3, dw4, db4, dw5, db5, None
+        _, _, dx3 = crw_hip.enc_conv3x3_map(s, d3h, d3l, *bw[0], 32, H, W, mode=1, planes=False, f32=True)  # [P, H*W, 32]
+        dw1, db1, dw2, db2 = crw_hip.enc_front_bwd_map(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3)
+        return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
 
 
 class _HipLinear(torch.autograd.Function):
@@ -170,11 +177,11 @@ class CNN(nn.Module):
         if self.hip_convs and x.is_cuda and x.dtype == torch.float32 and min(x.shape[-2:]) >= 7:
             if not torch.is_grad_enabled():
                 return self._head(self._hip_inference_trunk(x))
-            # training at another patch size: the 3x3 trunk (96.7 % of the flops) forward AND backward on the tiled HIP
-            # kernels, the small front end on PyTorch-ROCm ops with autograd
-            a2 = self.pool2(self.relu2(self.conv2(self.pool1(self.relu1(self.conv1(x))))))
-            gap = _HipMapTrunk.apply(a2, self.conv3.weight, self.conv3.bias, self.conv4.weight, self.conv4.bias,
-                                     self.conv5.weight, self.conv5.bias, 3 if self.hip_convs == "bf16x3" else 1)
+            # training at another patch size: the whole trunk forward AND backward on the tiled HIP kernels
+            c = [getattr(self, "conv%d" % i) for i in range(1, 6)]
+            gap = _HipMapEncoder.apply(x, c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[2].weight, c[2].bias,
+                                       c[3].weight, c[3].bias, c[4].weight, c[4].bias,
+                                       3 if self.hip_convs == "bf16x3" else 1)
             return self._head(gap)
         if self.hip_convs and x.is_cuda and not CNN._warned_fallback:
             # not silent: the caller believes it is on the hand-written kernels (set hip_convs = None to choose this path)

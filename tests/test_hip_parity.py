@@ -317,10 +317,10 @@ def test_encoder_inference_trunk_any_patch_size(hip, hw, split):
 @pytest.mark.parametrize("hw,ov", [((32, 32), (24, 0)), ((20, 27), (10, 0))])
 def test_training_at_other_patch_sizes_vs_oracle(hip, hw, ov):
     """Training step at patch sizes other than 16x16 (BASELINE config 5 is a 32x32-patch model, overlap (24,0),
-    scripts/test/test_mc1.py:19-26): conv3-5 forward, backward-data and weight gradients on the tiled HIP kernels
-    (`_HipMapTrunk`: 26x26 and 14x21 feature maps = 3x3 / 2x3 tiles with partial tiles in both directions), front end through
-    PyTorch autograd, HIP affinity + walk -- loss and every parameter gradient against the fp64 oracle, tolerances of
-    test_full_model_matches_reference."""
+    scripts/test/test_mc1.py:19-26): the whole conv trunk forward and backward on the tiled HIP kernels (`_HipMapEncoder`:
+    26x26 and 14x21 feature maps = 3x3 / 2x3 tiles with partial tiles in both directions; the front end's tiled backward
+    `crw_enc_front_bwd_map` included), HIP affinity + walk -- loss and every parameter gradient against the fp64 oracle,
+    tolerances of test_full_model_matches_reference."""
     import warnings
     import model as crw_model
     import encoder as crw_encoder
@@ -633,6 +633,37 @@ def test_encoder_front_kernels_match_torch(hip, cin, split):
         assert torch.equal(a_, b_)
     for got, ref in ((dw2, w2.grad), (db2, b2.grad), (dw1, w1.grad), (db1, b1.grad)):
         # plain bf16: rounding conv2's inputs can flip a max-pool arg-max, which re-routes a gradient
+        t = dict(rtol=2e-3, atol=2e-3 * ref.abs().max().item()) if split == 3 else \
+            dict(rtol=2e-1, atol=1.5e-1 * ref.abs().max().item())
+        torch.testing.assert_close(got.cpu().double(), ref, **t)
+
+
+@pytest.mark.parametrize("cin,hw", [(1, (20, 27)), (2, (32, 32)), (1, (16, 16)), (1, (9, 12))])
+@pytest.mark.parametrize("split", [3, 1])
+def test_front_backward_on_tiles_matches_torch(hip, cin, hw, split):
+    """conv1-ReLU-pool-conv2-ReLU-pool backward on patches of any size (`crw_enc_front_bwd_map`: units of 10x10 output tiles,
+    partial tiles, a one-tile 16x16 case and a map smaller than a tile) against fp64 torch autograd."""
+    import torch.nn.functional as TF
+    P = 5
+    h, w = hw
+    g = torch.Generator().manual_seed(100 * cin + h + split)
+    x = torch.randn(P, cin, h, w, generator=g)
+    w1 = (torch.randn(8, cin, 5, 5, generator=g) * 0.2).double().requires_grad_(True)
+    b1 = (torch.randn(8, generator=g) * 0.1).double().requires_grad_(True)
+    w2 = (torch.randn(32, 8, 5, 5, generator=g) * 0.07).double().requires_grad_(True)
+    b2 = (torch.randn(32, generator=g) * 0.1).double().requires_grad_(True)
+    a1 = TF.max_pool2d(TF.relu(TF.conv2d(x.double(), w1, b1, padding=1)), 2, 1)
+    y = TF.max_pool2d(TF.relu(TF.conv2d(a1, w2, b2, padding=1)), 2, 1)  # [P,32,h-6,w-6]
+    H, W = h - 6, w - 6
+    dy = torch.randn(P, H * W, 32, generator=g)
+    y.backward(dy.double().reshape(P, H, W, 32).permute(0, 3, 1, 2))
+    c = lambda t: t.detach().float().cuda()
+    w2f = hip.enc_front_pack(c(w2), split)
+    yh, yl = hip.enc_front_fwd_map(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2))
+    tol = dict(rtol=1e-4, atol=1e-4) if split == 3 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(_planes_value(yh, yl).cpu().double(), y.detach().permute(0, 2, 3, 1).reshape(P, H * W, 32), **tol)
+    dw1, db1, dw2, db2 = hip.enc_front_bwd_map(split, x.cuda(), c(w1), c(b1), w2f[:2], c(b2), w2f[2:], dy.cuda())
+    for got, ref in ((dw2, w2.grad), (db2, b2.grad), (dw1, w1.grad), (db1, b1.grad)):
         t = dict(rtol=2e-3, atol=2e-3 * ref.abs().max().item()) if split == 3 else \
             dict(rtol=2e-1, atol=1.5e-1 * ref.abs().max().item())
         torch.testing.assert_close(got.cpu().double(), ref, **t)
