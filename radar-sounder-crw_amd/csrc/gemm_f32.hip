@@ -300,7 +300,8 @@ constexpr int AT = 128, ATLD = AT + 1;  // affinity tile and the row stride of i
 // A[b,t] tile = ehat[b,t][m0..] ehat[b,t+1][n0..]^T / tau, plus (optional) the tile's partial softmax statistics:
 // per row the (max, sum exp) over the tile's valid columns -> rpart[mat][tn][row], per column over its rows -> cpart[mat][tm][col]
 __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restrict__ ehat, int T, int N, int C, float tau,
-                                                            float *__restrict__ A, float *__restrict__ part, int tiles) {
+                                                            float *__restrict__ A, float *__restrict__ part, int tiles,
+                                                            float *__restrict__ direct) {
   constexpr int LD = AT + 16;
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   float *As = lds_f, *Bs = lds_f + BK * LD, *tile = lds_f;  // the output tile reuses the operand space
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
     const int r = e >> 7, c = e & 127;
     if (m0 + r < N && n0 + c < N) Ab[(long)(m0 + r) * N + n0 + c] = tile[r * ATLD + c];
   }
-  if (!part) return;
+  if (!part && !direct) return;
   // threads 0..127: one tile row each; threads 128..255: one tile column each (both walks are bank-conflict free on ATLD)
   const int idx = tid & 127;
   const bool rows = tid < 128;
@@ -357,11 +358,15 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
   for (int j = 0; j < lim; ++j) sum += expf(src[j * step] - m);
   const int gi = (rows ? m0 : n0) + idx;
   if (gi < N) {
-    // part: [2 (row / column)][nmat][tiles][N][2]
     const long nmat = gridDim.y;
-    float *dst = part + ((((rows ? 0 : nmat) + amat) * tiles + (rows ? tn : tm)) * (long)N + gi) * 2;
-    dst[0] = m;
-    dst[1] = sum;
+    if (direct) {  // one tile per matrix (N <= 128): the partial IS the statistic -> dense [4][nmat][N], no merge launch
+      direct[((rows ? 0 : 2) * nmat + amat) * N + gi] = m;
+      direct[((rows ? 1 : 3) * nmat + amat) * N + gi] = sum;
+    } else {       // part: [2 (row / column)][nmat][tiles][N][2]
+      float *dst = part + ((((rows ? 0 : nmat) + amat) * tiles + (rows ? tn : tm)) * (long)N + gi) * 2;
+      dst[0] = m;
+      dst[1] = sum;
+    }
   }
 }
 
@@ -484,9 +489,10 @@ int launch_affinity_tiles(const float *ehat, int B, int T, int N, int C, float t
     }
     attr = true;
   }
+  const bool single = tiles == 1;
   hipLaunchKernelGGL(affinity_tile_kernel, dim3(tiles * tiles, nmat), dim3(256), lds, s, ehat, T, N, C, tau, A,
-                     stats ? part : nullptr, tiles);
-  if (stats) {
+                     (stats && !single) ? part : nullptr, tiles, (stats && single) ? stats : nullptr);
+  if (stats && !single) {
     const long n = 2L * nmat * N;
     hipLaunchKernelGGL(affinity_stats_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nmat, tiles, N, stats);
   }

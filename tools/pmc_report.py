@@ -28,8 +28,10 @@ def algorithmic(name):
         dy = E * co * (2 if (ci, co) == (128, 128) else 4)  # conv5: the activation hi plane stands for dY
         nslice = {(128, 128): 128, (64, 128): 256, (32, 64): 256}[(ci, co)]
         return "wgrad", ci, co, dy + E * ci * 4, nslice * co * ci * 9 * 4
-    if name.startswith("front_fwd_kernel"):
-        return "front_fwd", 1, 32, P * 256 * 4, E * 32 * 4
+    if name.startswith("front_fwd_kernel"):  # training forward also writes the 9968-byte saved record per patch
+        return "front_fwd", 1, 32, P * 256 * 4, E * 32 * 4 + P * 9968
+    if name.startswith("front_bwd_saved_kernel"):  # patch + saved record + the gradient planes in; per-WG partial weight gradients out
+        return "front_bwd", 1, 32, P * 256 * 4 + P * 9968 + E * 32 * 4, 256 * 6840 * 4
     if name.startswith("front_bwd_kernel"):
         return "front_bwd", 1, 32, P * 256 * 4 + E * 32 * 4, 256 * 6840 * 4
     return None
