@@ -12,6 +12,7 @@
 // Index quirk kept on purpose: indices address the truncated key list
 // [frame 0, last cxt frames] but are applied to the untruncated label list.
 #include "crw_common.h"
+#include <cstdlib>
 
 namespace crw {
 namespace {
@@ -157,6 +158,112 @@ __global__ __launch_bounds__(1024) void labelprop_gather_kernel(const float *__r
   }
 }
 
+// The same propagation with the soft labels of the most recent R frames (and of frame 0, the long-term frame every step
+// reads) kept in LDS, the step's (weight, index) lists prefetched one frame ahead into a double-buffered LDS copy, and the
+// arg-max read back from LDS: a frame costs LDS traffic and ONE barrier where the kernel above pays three L2 round trips
+// (gather, store acknowledge, arg-max reload) -- 10 us per frame at [T, N] = [256, 48].  Labels older than R frames are read
+// from L in global memory (written there by every frame as before; they are long since visible).  Same operations in the
+// same order: bit-identical results.
+constexpr int GATHER_NT = 256, GATHER_PF = 8;  // threads; prefetch registers per thread (knn * N <= 2048)
+__global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const float *__restrict__ seed,
+                                                                         const float *__restrict__ W,
+                                                                         const int32_t *__restrict__ I, int T, int N, int M,
+                                                                         int knn, int first_frame, float *L,
+                                                                         float *__restrict__ pred, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, NM = N * M, KN = knn * N;
+  float *l0 = sm, *ring = l0 + NM, *wbuf = ring + (long)R * NM;  // [NM], [R][NM], [2][KN]
+  int *ibuf = reinterpret_cast<int *>(wbuf + 2 * KN);              // [2][KN]
+  for (int it = tid; it < NM; it += GATHER_NT) {
+    float v;
+    if (seed) {
+      v = seed[it / M] == (float)(it % M) ? 1.f : 0.f;
+      st_l2(L + it, v);
+    } else {
+      v = ld_l2(L + it);
+    }
+    l0[it] = v;
+  }
+  if (seed)
+    for (int q = tid; q < N; q += GATHER_NT) pred[(long)q * T] = seed[q];
+  for (int e = tid; e < KN; e += GATHER_NT) {
+    wbuf[(first_frame & 1) * KN + e] = W[e];
+    ibuf[(first_frame & 1) * KN + e] = I[e];
+  }
+  __syncthreads();
+  const int RNM = R * NM;
+  for (int n = first_frame; n < T; ++n) {
+    const int cur = n & 1;
+    // next frame's lists: global -> registers now, -> LDS after this frame's arithmetic (unconditional, clamped loads)
+    const long nxt = (long)(min(n + 1, T - 1) - first_frame) * KN;
+    float pw[GATHER_PF];
+    int pi[GATHER_PF];
+#pragma unroll
+    for (int u = 0; u < GATHER_PF; ++u) {
+      const int e = min(tid + u * GATHER_NT, KN - 1);
+      pw[u] = W[nxt + e];
+      pi[u] = I[nxt + e];
+    }
+    // frames [lo_f, n - 1] live in the ring; a frame f sits at flat offset (f % R) * NM
+    const int lo_f = max(first_frame, n - R + 1);
+    const int lo_idx = lo_f * N;                       // first label-list row that is in the ring
+    const int epoch_base = (n / R - 1) * RNM;          // flat offset of the older of the (at most) two ring epochs in view
+    const float *wn = wbuf + cur * KN;
+    const int *in = ibuf + cur * KN;
+    float *slot = ring + (n % R) * NM;
+    for (int it = tid; it < NM; it += GATHER_NT) {
+      const int q = it / M, c = it % M;
+      float p = 0.f;
+      // four neighbours at a time: their (index, weight) reads and then their label reads are independent LDS round trips
+      // (one neighbour after the other is two dependent round trips each: 3 of the 4 us a frame took); the sum stays in j order
+      for (int j0 = 0; j0 < knn; j0 += 4) {
+        int idx[4];
+        float w[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jj = min(j0 + u, knn - 1);
+          idx[u] = in[jj * N + q];
+          w[u] = wn[jj * N + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // frame 0 sits in l0 = sm[0, NM), the ring behind it; a label older than the ring comes from global memory
+          int off = idx[u] * M + c - epoch_base;
+          if (off >= RNM) off -= RNM;
+          const bool first = idx[u] < N, old = !first && idx[u] < lo_idx;
+          const int a = first ? idx[u] * M + c : (old ? 0 : NM + off);
+          v[u] = sm[a];
+          if (old) v[u] = ld_l2(L + (long)idx[u] * M + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < knn) p += v[u] * w[u];
+      }
+      st_l2(L + ((long)n * N + q) * M + c, p);
+      slot[it] = p;
+    }
+#pragma unroll
+    for (int u = 0; u < GATHER_PF; ++u) {
+      const int e = tid + u * GATHER_NT;
+      if (e < KN) {
+        wbuf[(cur ^ 1) * KN + e] = pw[u];
+        ibuf[(cur ^ 1) * KN + e] = pi[u];
+      }
+    }
+    __syncthreads();
+    for (int q = tid; q < N; q += GATHER_NT) {
+      const float *row = slot + q * M;
+      float bv = row[0];
+      int bi = 0;
+      for (int c = 1; c < M; ++c) {
+        const float v = row[c];
+        if (v > bv) { bv = v; bi = c; }
+      }
+      pred[(long)q * T + n] = (float)bi;
+    }
+  }
+}
+
 // xent[a, i] = logsumexp_c A_i[c, a] - A_i[a, a],  A_i[c, a] = <ehat[i,c,0:C-1], ehat[i,a,1:C]> / 0.1
 __global__ __launch_bounds__(64) void xent_metric_kernel(const float *__restrict__ ehat, int T, int N, int C,
                                                          float *__restrict__ xent) {
@@ -207,6 +314,27 @@ int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, in
   if (!W || !I || !L || !pred || T < 2 || N < 1 || M < 1 || knn < 1 || first_frame < 1 || first_frame >= T ||
       (!seed && first_frame < 1))
     return CRW_EINVAL;
+  // LDS-resident form when the lists of a frame fit the prefetch registers and at least a few frames fit the ring
+  const long NM = (long)N * M, KN = (long)knn * N;
+  const long budget = 150 * 1024 - 16 * KN;  // bytes left for frame 0 + the ring after the two (weight, index) list copies
+  long R = budget > 0 ? budget / (4 * NM) - 1 : 0;
+  if (R > T) R = T;
+  static const char *force_global = getenv("CRW_LABELPROP_GATHER_GLOBAL");  // diagnostics: the L2-round-trip kernel
+  if (KN <= (long)GATHER_NT * GATHER_PF && R >= 4 && (long)T * N < (1L << 30) / M && !force_global) {
+    const size_t lds = (size_t)(4 * (NM * (R + 1) + 4 * KN));
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void *)labelprop_gather_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+          hipSuccess) {
+        g_last_hip_error = (int)hipGetLastError();
+        return CRW_EHIP;
+      }
+      attr = true;
+    }
+    hipLaunchKernelGGL(labelprop_gather_lds_kernel, dim3(1), dim3(GATHER_NT), lds, (hipStream_t)stream, seed, W, I, T, N, M,
+                       knn, first_frame, L, pred, (int)R);
+    return check_launch();
+  }
   hipLaunchKernelGGL(labelprop_gather_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seed, W, I, T, N, M, knn,
                      first_frame, L, pred);
   return check_launch();
