@@ -14,6 +14,7 @@
 // Fragment maps (gfx950, 16x16x4 f32): A lane l -> A[row l&15][k l>>4], B lane l -> B[k l>>4][col l&15],
 // C/D reg r of lane l -> C[row (l>>4)*4 + r][col l&15].
 #include "crw_common.h"
+#include <cstdlib>
 
 namespace crw {
 
@@ -295,10 +296,122 @@ __device__ inline void mfma_block(const float *As, const float *Bs, int wm, int 
   }
 }
 
-constexpr int AT = 128, ATLD = AT + 1;  // affinity tile and the row stride of its LDS image (conflict-free row AND column walks)
+// ---- "bf16 x 6": fp32 products on the bf16 matrix cores -------------------------------------------------------------
+// An fp32 value is split into three bf16 terms, x = h + m + l exactly (8 + 8 + 8 significand bits), and a product a * b
+// is accumulated as al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh in fp32: the dropped terms (ml, lm, ll) are below
+// 2^-24 |a b|, i.e. the result is fp32-grade like the 16x16x4 fp32 MFMA, at 6/16 of its matrix-pipe time (the fp32 MFMA
+// runs at 1/16 of the bf16 rate).  Used by the affinity build and its backward at large node counts, where those two
+// fp32-MFMA kernels were 10 % of the plain-bf16 chain step at N = 4096.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+__device__ inline uint16_t bf_of(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ inline float f_of(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ inline void split3(float x, uint16_t &h, uint16_t &m, uint16_t &l) {
+#pragma clang fp contract(off)
+  h = bf_of(x);
+  const float r1 = x - f_of(h);
+  m = bf_of(r1);
+  l = bf_of(r1 - f_of(m));
+}
+// bf16 operand plane in LDS: [R rows][32 k], 64-byte rows, 16-byte chunks swizzled so that the ds_read_b128 lane groups of
+// a fragment are conflict-free (same scheme as the 32-deep k-tiles of gemm_bf16.hip)
+constexpr int X6K = 32;
+__device__ inline int x6_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ ((row & 8) ? 3 : 0)); }
+// four consecutive k (k0 = 4 kq) of one row -> the three planes (plane stride PL bytes)
+template <int PL>
+__device__ inline void x6_put4(char *planes, int row, int kq, float4 v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint16_t h[4], m[4], l[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) split3(x[u], h[u], m[u], l[u]);
+  char *dst = planes + x6_off(row, kq >> 1) + 8 * (kq & 1);
+  *reinterpret_cast<uint2 *>(dst) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+  *reinterpret_cast<uint2 *>(dst + PL) = uint2{(uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16)};
+  *reinterpret_cast<uint2 *>(dst + 2 * PL) = uint2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+}
+// one 32-deep k-step of a wave's TM x TN block of 16 x 16 tiles from the planes of A (rows wm..) and B (rows wn..)
+template <int TM, int TN, int PLA, int PLB>
+__device__ inline void x6_block(const char *Ap, const char *Bp, int wm, int wn, int lane, f32x4 (&acc)[TM][TN]) {
+  const int r16 = lane & 15, g = lane >> 4;
+  bf8v ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const char *p = Ap + x6_off(wm + 16 * i + r16, g);
+    ah[i] = *reinterpret_cast<const bf8v *>(p);
+    am[i] = *reinterpret_cast<const bf8v *>(p + PLA);
+    al[i] = *reinterpret_cast<const bf8v *>(p + 2 * PLA);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const char *p = Bp + x6_off(wn + 16 * j + r16, g);
+    bh[j] = *reinterpret_cast<const bf8v *>(p);
+    bm[j] = *reinterpret_cast<const bf8v *>(p + PLB);
+    bl[j] = *reinterpret_cast<const bf8v *>(p + 2 * PLB);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x4 c = acc[i][j];
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bm[j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm[j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+      acc[i][j] = c;
+    }
+}
+// R rows x 32 k of a k-contiguous fp32 operand X[(r0 + r) * ld + k0 + k]: R * 8 float4, loaded unconditionally at clamped
+// addresses (rows >= rmax repeat the last row: their products are masked at the store; k >= kmax reads as zero)
+template <int R>
+struct X6StagerK {
+  static constexpr int PER = R * 8 / 256;
+  float4 v[PER];
+  __device__ inline void load(const float *__restrict__ X, long ld, int r0, int k0, int rmax, int kmax, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + i * 256, r = e >> 3, k = k0 + 4 * (e & 7);
+      const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(r0 + r, rmax - 1) * ld + min(k, kmax - 4));
+      v[i] = k < kmax ? t : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  template <int PL>
+  __device__ inline void store(char *planes, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + i * 256;
+      x6_put4<PL>(planes, e >> 3, e & 7, v[i]);
+    }
+  }
+};
+// R rows x 32 k of an r-contiguous operand X[(k0 + k) * ld + r0 + r] (R = 128): one 4 k x 4 r block per thread, transposed in
+// registers so that every row receives 4 consecutive k (rmax % 4 == 0; k >= kmax and r >= rmax read as zero)
+struct X6StagerR {
+  float4 v[4];
+  __device__ inline void load(const float *__restrict__ X, long ld, int r0, int k0, int rmax, int kmax, int tid) {
+    const int rq = tid & 31, kq = tid >> 5, r = r0 + 4 * rq;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 4 * kq + u;
+      const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(k, kmax - 1) * ld + min(r, rmax - 4));
+      v[u] = (k < kmax && r < rmax) ? t : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  template <int PL>
+  __device__ inline void store(char *planes, int tid) const {
+    const int rq = tid & 31, kq = tid >> 5;
+    x6_put4<PL>(planes, 4 * rq + 0, kq, float4{v[0].x, v[1].x, v[2].x, v[3].x});
+    x6_put4<PL>(planes, 4 * rq + 1, kq, float4{v[0].y, v[1].y, v[2].y, v[3].y});
+    x6_put4<PL>(planes, 4 * rq + 2, kq, float4{v[0].z, v[1].z, v[2].z, v[3].z});
+    x6_put4<PL>(planes, 4 * rq + 3, kq, float4{v[0].w, v[1].w, v[2].w, v[3].w});
+  }
+};
+
+constexpr int AT = 128, ATLD = AT + 4;  // affinity tile and the row stride of its LDS image (16-byte aligned rows; the accumulator writes are conflict-free)
 
 // A[b,t] tile = ehat[b,t][m0..] ehat[b,t+1][n0..]^T / tau, plus (optional) the tile's partial softmax statistics:
 // per row the (max, sum exp) over the tile's valid columns -> rpart[mat][tn][row], per column over its rows -> cpart[mat][tm][col]
+template <bool X6>  // X6: products on the bf16 matrix cores in three-term splits (C % 32 == 0), else fp32 MFMA
 __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restrict__ ehat, int T, int N, int C, float tau,
                                                             float *__restrict__ A, float *__restrict__ part, int tiles,
                                                             float *__restrict__ direct) {
@@ -316,6 +429,36 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (X6) {
+    constexpr int PL = AT * 64;  // one bf16 plane of a 128-row operand, 32 deep
+    char *Ap = reinterpret_cast<char *>(lds_f), *Bp = Ap + 3 * PL;
+    // two register sets: the loads of chunk kt + 2 are issued while chunk kt is multiplied, so a load has two MFMA
+    // blocks to land (one block is shorter than a load's round trip; with one set every chunk waited for its data)
+    X6StagerK<AT> sa0, sb0, sa1, sb1;
+    const int nk = C / X6K;
+    sa0.load(E0, C, m0, 0, N, C, tid);
+    sb0.load(E1, C, n0, 0, N, C, tid);
+    sa1.load(E0, C, m0, min(1, nk - 1) * X6K, N, C, tid);
+    sb1.load(E1, C, n0, min(1, nk - 1) * X6K, N, C, tid);
+    for (int kt = 0; kt < nk; kt += 2) {
+      sa0.store<PL>(Ap, tid);
+      sb0.store<PL>(Bp, tid);
+      __syncthreads();
+      sa0.load(E0, C, m0, min(kt + 2, nk - 1) * X6K, N, C, tid);  // unconditional (clamped): unused past the end
+      sb0.load(E1, C, n0, min(kt + 2, nk - 1) * X6K, N, C, tid);
+      x6_block<4, 4, PL, PL>(Ap, Bp, wm, wn, lane, acc);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        sa1.store<PL>(Ap, tid);
+        sb1.store<PL>(Bp, tid);
+        __syncthreads();
+        sa1.load(E0, C, m0, min(kt + 3, nk - 1) * X6K, N, C, tid);
+        sb1.load(E1, C, n0, min(kt + 3, nk - 1) * X6K, N, C, tid);
+        x6_block<4, 4, PL, PL>(Ap, Bp, wm, wn, lane, acc);
+        __syncthreads();
+      }
+    }
+  } else {
   BoundStager<AT> sa, sb;
   const int nk = (C + BK - 1) / BK;
   sa.load(E0, C, m0, 0, true, N, C, tid);
@@ -331,31 +474,102 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
     mfma_block<4, 4, LD, LD>(As, Bs, wm, wn, lane, acc);
     __syncthreads();
   }
-  // accumulators -> LDS image of the tile (already divided by tau)
+  }
+  // ---- epilogue: the tile goes to global memory through an LDS image (row-contiguous 16-byte stores), its partial softmax
+  // statistics come straight from the accumulators: per wave a row's (max, sum exp) over the wave's 64 columns is an
+  // in-register reduction over j plus a 16-lane butterfly, a column's over the wave's 64 rows one over (i, r) plus the 4 lane
+  // groups; the two waves that share a row (column) range meet in LDS.  (Walking the LDS image row by row and column by column
+  // with one thread each -- the first version -- cost four times the MFMA time of the tile.)
+  float v[4][4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        tile[(wm + 16 * i + 4 * (lane >> 4) + r) * ATLD + wn + 16 * j + (lane & 15)] = acc[i][j][r] / tau;
+      for (int r = 0; r < 4; ++r) v[i][j][r] = acc[i][j][r] / tau;
+  const int g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(wm + 16 * i + 4 * g + r) * ATLD + wn + 16 * j + r16] = v[i][j][r];
+  float *rpart = tile + AT * ATLD, *cpart = rpart + 2 * AT * 2;  // [2 column halves][128 rows][m, s], [2 row halves][128 cols][m, s]
+  if (part || direct) {
+    bool cok[4], rok[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cok[j] = n0 + wn + 16 * j + r16 < N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rok[i][r] = m0 + wm + 16 * i + 4 * g + r < N;
+    // rows: over this wave's columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = cok[j] ? fmaxf(m, v[i][j][r]) : m;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += cok[j] ? expf(v[i][j][r] - m) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        if (r16 == 0) {
+          float *dst = rpart + ((wn >> 6) * AT + wm + 16 * i + 4 * g + r) * 2;
+          dst[0] = m;
+          dst[1] = sum;
+        }
+      }
+    // columns: over this wave's rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = rok[i][r] ? fmaxf(m, v[i][j][r]) : m;
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += rok[i][r] ? expf(v[i][j][r] - m) : 0.f;
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      if (g == 0) {
+        float *dst = cpart + ((wm >> 6) * AT + wn + 16 * j + r16) * 2;
+        dst[0] = m;
+        dst[1] = sum;
+      }
+    }
+  }
   __syncthreads();
   float *Ab = A + amat * (long)N * N;
-  for (int e = tid; e < AT * AT; e += 256) {  // a wave writes 64 consecutive columns of a row
-    const int r = e >> 7, c = e & 127;
-    if (m0 + r < N && n0 + c < N) Ab[(long)(m0 + r) * N + n0 + c] = tile[r * ATLD + c];
+  if ((N & 3) == 0) {  // a wave writes 512 contiguous bytes of two rows per instruction
+    for (int e = tid; e < AT * AT / 4; e += 256) {
+      const int r = e >> 5, c = 4 * (e & 31);
+      if (m0 + r < N && n0 + c < N)
+        *reinterpret_cast<float4 *>(Ab + (long)(m0 + r) * N + n0 + c) = *reinterpret_cast<const float4 *>(tile + r * ATLD + c);
+    }
+  } else {
+    for (int e = tid; e < AT * AT; e += 256) {
+      const int r = e >> 7, c = e & 127;
+      if (m0 + r < N && n0 + c < N) Ab[(long)(m0 + r) * N + n0 + c] = tile[r * ATLD + c];
+    }
   }
   if (!part && !direct) return;
-  // threads 0..127: one tile row each; threads 128..255: one tile column each (both walks are bank-conflict free on ATLD)
+  // threads 0..127: one tile row each; threads 128..255: one tile column each: merge the two half-tile partials
   const int idx = tid & 127;
   const bool rows = tid < 128;
-  const int lim = rows ? min(AT, N - n0) : min(AT, N - m0);   // valid extent along the walk
-  const int step = rows ? 1 : ATLD;
-  const float *src = tile + (rows ? idx * ATLD : idx);
-  float m = -INFINITY;
-  for (int j = 0; j < lim; ++j) m = fmaxf(m, src[j * step]);
-  float sum = 0.f;
-  for (int j = 0; j < lim; ++j) sum += expf(src[j * step] - m);
+  const float *pp = (rows ? rpart : cpart) + idx * 2;
+  const float ma = pp[0], sa = pp[1], mb = pp[AT * 2], sb = pp[AT * 2 + 1];
+  const float m = fmaxf(ma, mb);
+  const float sum = (sa > 0.f ? sa * expf(ma - m) : 0.f) + (sb > 0.f ? sb * expf(mb - m) : 0.f);
   const int gi = (rows ? m0 : n0) + idx;
   if (gi < N) {
     const long nmat = gridDim.y;
@@ -437,6 +651,59 @@ __global__ __launch_bounds__(256) void affinity_bwd_tile_kernel(const float *__r
       }
 }
 
+// The same on the bf16 matrix cores (three-term splits of dA and ehat): C = 128 only (one 128 x 128 output tile per workgroup)
+__global__ __launch_bounds__(256) void affinity_bwd_x6_kernel(const float *__restrict__ dA, const float *__restrict__ ehat,
+                                                              int T, int N, float tau, float *__restrict__ dehat) {
+  constexpr int C = 128, PL = AT * 64;
+  __shared__ __attribute__((aligned(16))) char lds_c[6 * PL];
+  char *Ap = lds_c, *Bp = lds_c + 3 * PL;
+  const int m0 = blockIdx.x * AT;
+  const long bt = blockIdx.y, b = bt / T, t = bt % T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  X6StagerK<AT> sak;
+  X6StagerR sar, sb;
+  const long NN = (long)N * N, NC = (long)N * C;
+  const int nk = (N + X6K - 1) / X6K;
+  for (int prod = 0; prod < 2; ++prod) {
+    if (prod == 0 ? t == T - 1 : t == 0) continue;  // block-uniform
+    // product 0: dA[b,t] (row n, k = m), k-contiguous; product 1: dA[b,t-1]^T = dA[b,t-1][m][n], r-contiguous
+    const float *X = dA + (b * (T - 1) + (prod == 0 ? t : t - 1)) * NN;
+    const float *E = ehat + (b * T + (prod == 0 ? t + 1 : t - 1)) * NC;  // [k = node][c]: r-contiguous, 128 "rows" c
+    if (prod == 0) sak.load(X, N, m0, 0, N, N, tid);
+    else sar.load(X, N, m0, 0, N, N, tid);
+    sb.load(E, C, 0, 0, C, N, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (prod == 0) sak.store<PL>(Ap, tid);
+      else sar.store<PL>(Ap, tid);
+      sb.store<PL>(Bp, tid);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (prod == 0) sak.load(X, N, m0, (kt + 1) * X6K, N, N, tid);
+        else sar.load(X, N, m0, (kt + 1) * X6K, N, N, tid);
+        sb.load(E, C, 0, (kt + 1) * X6K, C, N, tid);
+      }
+      x6_block<4, 4, PL, PL>(Ap, Bp, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  }
+  float *D = dehat + bt * NC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+        if (row < N) D[(long)row * C + wn + 16 * j + (lane & 15)] = acc[i][j][r] / tau;
+      }
+}
+
 // largest tile (128 / 64 / 32) that divides n and still yields a well-filled grid
 int pick_tile(int n, long batch_times_prob) {
   const int cand[3] = {128, 64, 32};
@@ -471,6 +738,13 @@ int launch_edge_gemm(const EdgeGemm &g, int batch, hipStream_t s) {
   return check_launch();
 }
 
+// Large node counts run the affinity products on the bf16 matrix cores in three-term splits (fp32-grade, see "bf16 x 6");
+// small ones keep the fp32 MFMA (launch-bound there, and bit-identical to earlier rounds).  CRW_AFFINITY_F32=1 forces fp32.
+bool affinity_on_bf16(int N, int C) {
+  static const bool force_f32 = getenv("CRW_AFFINITY_F32") != nullptr;
+  return !force_f32 && N >= 256 && C % 32 == 0;
+}
+
 size_t affinity_part_floats(int B, int T, int N) {
   const size_t tiles = (N + AT - 1) / AT;
   return (size_t)2 * B * (T - 1) * tiles * N * 2;
@@ -480,18 +754,23 @@ int launch_affinity_tiles(const float *ehat, int B, int T, int N, int C, float t
                           hipStream_t s) {
   if (C % 4 || C < 4 || (stats && !part)) return CRW_EINVAL;
   const int tiles = (N + AT - 1) / AT, nmat = B * (T - 1);
-  const size_t lds = sizeof(float) * (size_t)(AT * ATLD > 2 * BK * (AT + 16) ? AT * ATLD : 2 * BK * (AT + 16));
+  const size_t lds = sizeof(float) * (size_t)(AT * ATLD + 2 * 2 * AT * 2);  // tile image + the half-tile partials (>= the operand planes)
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void *)affinity_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)affinity_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)affinity_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
   const bool single = tiles == 1;
-  hipLaunchKernelGGL(affinity_tile_kernel, dim3(tiles * tiles, nmat), dim3(256), lds, s, ehat, T, N, C, tau, A,
-                     (stats && !single) ? part : nullptr, tiles, (stats && single) ? stats : nullptr);
+  if (affinity_on_bf16(N, C))
+    hipLaunchKernelGGL(affinity_tile_kernel<true>, dim3(tiles * tiles, nmat), dim3(256), lds, s, ehat, T, N, C, tau, A,
+                       (stats && !single) ? part : nullptr, tiles, (stats && single) ? stats : nullptr);
+  else
+    hipLaunchKernelGGL(affinity_tile_kernel<false>, dim3(tiles * tiles, nmat), dim3(256), lds, s, ehat, T, N, C, tau, A,
+                       (stats && !single) ? part : nullptr, tiles, (stats && single) ? stats : nullptr);
   if (stats && !single) {
     const long n = 2L * nmat * N;
     hipLaunchKernelGGL(affinity_stats_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nmat, tiles, N, stats);
@@ -503,6 +782,10 @@ int launch_affinity_bwd_tiles(const float *dA, const float *ehat, int B, int T, 
                               hipStream_t s) {
   if (N % 4 || N < 4) return CRW_EINVAL;
   const dim3 grid((N + AT - 1) / AT, B * T);
+  if (C == 128 && affinity_on_bf16(N, C)) {
+    hipLaunchKernelGGL(affinity_bwd_x6_kernel, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat);
+    return check_launch();
+  }
   switch (C) {
     case 32: hipLaunchKernelGGL(affinity_bwd_tile_kernel<1>, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat); break;
     case 64: hipLaunchKernelGGL(affinity_bwd_tile_kernel<2>, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat); break;

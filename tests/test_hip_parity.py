@@ -136,12 +136,14 @@ def test_bf16_chain_modes_on_256_tiles_match_oracle(hip, chain):
 
 
 @pytest.mark.parametrize("B,T,N,C,tau", [(2, 4, 63, 128, 0.01), (1, 3, 130, 64, 0.05), (2, 3, 257, 32, 0.1), (1, 5, 512, 128, 0.02),
-                                         (1, 3, 40, 20, 0.07)])
+                                         (1, 3, 40, 20, 0.07), (1, 3, 300, 128, 0.01), (2, 3, 260, 64, 0.05)])
 def test_affinity_tiles_and_fused_statistics(hip, B, T, N, C, tau):
-    """crw_affinity_fwd on the fp32-MFMA tiles: logits against fp64, the softmax statistics of its epilogue (per-tile partials
-    merged in tile order) against a direct computation, and the walk fed with them against the walk that computes its own
-    (both softmax paths: imported statistics / stats kernel).  Also the tiled affinity backward (N % 4 == 0, C in {32, 64,
-    128}) and the bounds-checked fallback against fp64."""
+    """crw_affinity_fwd on the 128-row tiles -- fp32 MFMA below 256 nodes, three-term bf16 splits on the bf16 matrix cores from
+    256 nodes on (C % 32 == 0): logits against fp64, the softmax statistics of its epilogue (per-tile partials merged in tile
+    order) against a direct computation, and the walk fed with them against the walk that computes its own (both softmax
+    paths: imported statistics / stats kernel).  Also the tiled affinity backward (N % 4 == 0: fp32 MFMA at C in {32, 64}, or
+    below 256 nodes; bf16 splits at C = 128 from 256 nodes on, here with a ragged last k-chunk at N = 300) and the
+    bounds-checked fallback against fp64."""
     g = torch.Generator().manual_seed(N + C)
     emb = (torch.randn(1, 1, N, C, generator=g) + 0.6 * torch.randn(B, T, N, C, generator=g)).float()
     A, ehat, norm, stats = hip.affinity_fwd(emb.cuda(), tau)
