@@ -231,7 +231,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   constexpr int KCH = CIN / 32;                           // 32-deep k-steps per tap
   // rows dealt out by bank residue (slot_pixel) where a wave owns all 7 row tiles; with row tiles split over waves
   // (64 / 32 output channels at 8 waves) the wave-uniform tile index costs the short epilogue more than the reads gain
-  constexpr bool PERM = !MAP && WM == 1;
+  // (measured, tools/r02_conv_ab.sh: dealing by residue with split row tiles gains 2-3 % on conv4's backward-data -- 36 k-steps
+  // per patch -- and nothing on the 9 / 18-step layers)
+  constexpr bool PERM = !MAP && (WM == 1 || (MODE == 1 && CIN == 128 && COUT == 64));
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   int p0 = blockIdx.x, ty0 = 0, tx0 = 0;  // patch; MAP: origin of this workgroup's output tile in the map
