@@ -20,6 +20,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a ONE-GPU box (tests / tools only): every rank on device 0, exchange over gloo
+    # (RCCL refuses two ranks on one device).  CRW_DIST_REHEARSAL=1 python -m torch.distributed.run --nproc-per-node 2 bench.py ...
+    if os.environ.get("CRW_DIST_REHEARSAL"):
+        backend, local = "gloo", 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

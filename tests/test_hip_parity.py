@@ -884,6 +884,32 @@ def test_flat_gradient_all_reduce_on_rccl(hip, tmp_path):
         tdist.destroy_process_group()
 
 
+def test_bench_two_rank_control_flow_rehearsal(hip):
+    """bench.py's N > 1 path (launcher env, sharded radargrams, flat-gradient exchange every step, barrier + max-over-ranks timing,
+    one JSON line from rank 0) run as TWO ranks -- on this box's one GPU over gloo (CRW_DIST_REHEARSAL: RCCL refuses two ranks on
+    one device; the RCCL collective itself is test_flat_gradient_all_reduce_on_rccl).  Child processes, 2 ranks on the card."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CRW_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"].startswith("dp2") and "cpu_baseline" not in d
+    # whole-job aggregate: both ranks' columns over the slower rank's time
+    assert abs(d["value"] - 2 * d["config"]["columns_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert np.isfinite(d["config"]["loss"])
+
+
 def test_train_entrypoint_two_steps_vs_oracle(hip, tmp_path):
     """`scripts/train.py main(args)` (the entrypoint north_star keeps; reference scripts/train.py:39-93) for two steps at
     BASELINE config 2 (512x1024 radargram, T = 16, 16x16 patches, overlap (8,0), batch 8, tau 0.01, Adam 1e-3): the two step
