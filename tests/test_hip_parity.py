@@ -136,13 +136,14 @@ def test_bf16_chain_modes_on_256_tiles_match_oracle(hip, chain):
 
 
 @pytest.mark.parametrize("B,T,N,C,tau", [(2, 4, 63, 128, 0.01), (1, 3, 130, 64, 0.05), (2, 3, 257, 32, 0.1), (1, 5, 512, 128, 0.02),
-                                         (1, 3, 40, 20, 0.07), (1, 3, 300, 128, 0.01), (2, 3, 260, 64, 0.05)])
+                                         (1, 3, 40, 20, 0.07), (1, 3, 300, 128, 0.01), (2, 3, 260, 64, 0.05), (1, 260, 300, 128, 0.05)])
 def test_affinity_tiles_and_fused_statistics(hip, B, T, N, C, tau):
     """crw_affinity_fwd on the 128-row tiles -- fp32 MFMA below 256 nodes, three-term bf16 splits on the bf16 matrix cores from
     256 nodes on (C % 32 == 0): logits against fp64, the softmax statistics of its epilogue (per-tile partials merged in tile
     order) against a direct computation, and the walk fed with them against the walk that computes its own (both softmax
     paths: imported statistics / stats kernel).  Also the tiled affinity backward (N % 4 == 0: fp32 MFMA at C in {32, 64}, or
-    below 256 nodes; bf16 splits at C = 128 from 256 nodes on, here with a ragged last k-chunk at N = 300) and the
+    below 256 nodes; bf16 splits at C = 128 from 256 nodes on, here with a ragged last k-chunk at N = 300 and with more
+    workgroups than the chip holds at once: T = 260) and the
     bounds-checked fallback against fp64."""
     g = torch.Generator().manual_seed(N + C)
     emb = (torch.randn(1, 1, N, C, generator=g) + 0.6 * torch.randn(B, T, N, C, generator=g)).float()
@@ -155,10 +156,11 @@ def test_affinity_tiles_and_fused_statistics(hip, B, T, N, C, tau):
     rsum, csum = (Ad - rmax[..., None]).exp().sum(-1), (Ad - cmax[..., None, :]).exp().sum(-2)
     for got, want in zip(stats, (rmax, rsum, cmax, csum)):
         torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-6)
-    l0, _, At0 = hip.walk_fwd(A, want_At=True)
-    l1, _, At1 = hip.walk_fwd(A, want_At=True, stats=stats)
-    assert abs(l0.item() - l1.item()) <= 1e-6 * max(1.0, abs(l0.item()))
-    torch.testing.assert_close(At0, At1, rtol=1e-5, atol=1e-7)
+    if T <= 16:  # (the T = 260 case is there for the backward's grid; a 258-product chain amplifies the statistics' last bits)
+        l0, _, At0 = hip.walk_fwd(A, want_At=True)
+        l1, _, At1 = hip.walk_fwd(A, want_At=True, stats=stats)
+        assert abs(l0.item() - l1.item()) <= 1e-6 * max(1.0, abs(l0.item()))
+        torch.testing.assert_close(At0, At1, rtol=1e-5, atol=1e-7)
     dA = torch.randn(B, T - 1, N, N, generator=g).float()
     demb = hip.affinity_bwd(dA.cuda(), ehat, norm, tau)
     deh = torch.zeros_like(eh)
