@@ -175,6 +175,47 @@ def test_pelt_rbf_restatement():
     assert crw_utils.change_point(torch.zeros(4, 30)) is None
 
 
+def test_pelt_pruning_keeps_the_exact_optimum():
+    """PELT's defining property (Killick et al. 2012): with pruning it still returns the exact minimiser of
+    sum of segment costs + pen * (number of segments) over the admissible grid (breakpoints at multiples of `jump`, segments of at
+    least `min_size`).  Checked against the unpruned dynamic programme on random multi-regime signals and several penalties."""
+    import pelt
+    rng = np.random.default_rng(7)
+
+    def optimum(sig, pen, min_size=2, jump=5):
+        n = len(sig)
+        gram = pelt.rbf_gram(sig)
+
+        def cost(a, b):
+            blk = gram[a:b, a:b]
+            return np.trace(blk) - blk.sum() / (b - a)
+        ends = [k for k in range(0, n, jump) if k >= min_size] + [n]
+        best = {0: (0.0, ())}
+        for e in ends:
+            cands = [(best[t][0] + cost(t, e) + pen, best[t][1] + (e,)) for t in best if e - t >= min_size and t < e]
+            if cands:
+                best[e] = min(cands, key=lambda c: c[0])
+        return best[n]
+
+    def total(sig, bks, pen):
+        gram = pelt.rbf_gram(sig)
+        c, a = 0.0, 0
+        for b in bks:
+            blk = gram[a:b, a:b]
+            c += np.trace(blk) - blk.sum() / (b - a) + pen
+            a = b
+        return c
+
+    for trial in range(6):
+        levels = rng.normal(0, 2.0, size=rng.integers(1, 5))
+        sig = np.concatenate([rng.normal(m, 0.3, size=rng.integers(8, 40)) for m in levels])
+        for pen in (0.5, 5.0, 20.0):
+            got = pelt.pelt_rbf(sig, pen=pen)
+            want_cost, want_bks = optimum(sig, pen)
+            assert got[-1] == len(sig) and all(b % 5 == 0 for b in got[:-1])
+            assert abs(total(sig, got, pen) - want_cost) <= 1e-9 * max(1.0, abs(want_cost)), (trial, pen, got, want_bks)
+
+
 SEGMENT_CASES = ["segment_ds0_reverse", "segment_ds1_reverse", "segment_ds3_reverse", "segment_ds0_correction",
                  "segment_ds3_correction_reverse"]
 
