@@ -190,6 +190,14 @@ __device__ inline bool slot_pixel(int tile, int row, int &y, int &x) {
   return q < 4 || L == 3;
 }
 
+template <int N, class F>
+__device__ inline void static_for(F &&f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 struct ConvArgs {
   const uint16_t *xh, *xl;   // [P][100][CIN] input planes
   const uint16_t *wh, *wl;   // weights in fragment order (pack_weights_kernel; flipped/transposed for backward-data)
@@ -214,8 +222,16 @@ struct ConvArgs {
 // MAP = true: the same kernel on feature maps of any size (other patch sizes than 16x16, e.g. the 26x26 maps of
 // 32x32 patches): workgroup = (patch, 10x10 output tile); the 12x12 input window is gathered from the map with
 // zeros outside it, only in-map output pixels are stored, `gap` receives per-tile SUMS (forward only).
+// waves per SIMD the register allocation aims at: 4 (two 8-wave workgroups per CU, what the LDS of the 128-channel layers allows);
+// 6 for the 8-wave kernels of the 32 <-> 64 channel layers: their 44 KB of LDS admit three workgroups, and with the shorter
+// look-aheads below they fit 80 registers without spills (conv3 forward 239 -> 219 us inside the step: these layers spend under
+// 40 % of a workgroup's life in the k-loop, so a third workgroup per CU buys more than the look-aheads cost)
+template <int CIN, int COUT, int NW, bool MAP>
+constexpr int conv_waves_per_simd() {
+  return (!MAP && NW == 8 && CIN <= 64 && COUT <= 64) ? 6 : NW / 2;
+}
 template <int SPLIT, int CIN, int COUT, int MODE, int NW, bool MAP = false>
-__global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>())) void conv3x3_kernel(ConvArgs a) {
   constexpr int NT = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
@@ -343,12 +359,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
   };
 
   constexpr int NSTEP = 9 * KCH;
-  constexpr int AHEAD = 4;  // weight fragments are requested 4 k-steps before use
+  constexpr bool OCC6 = conv_waves_per_simd<CIN, COUT, NW, MAP>() == 6;  // 80 registers: shorter look-aheads
+  constexpr int AHEAD = OCC6 ? (CIN == 32 ? 1 : 2) : 4;  // weight fragments are requested AHEAD k-steps before use
   // Activation fragments are read from LDS DIST row tiles before the MFMAs that consume them (the compiler,
   // left alone, issues them one tile = 96 cycles ahead: less than the LDS latency, so a workgroup alone in
   // its k-loop kept the matrix pipe only ~55 % busy).  The first DIST tiles of the NEXT k-step are read
   // during the last tiles of this one and carried in nah/nal.
-  constexpr int DIST = MTW < 3 ? MTW : 3;
+  constexpr int DIST = OCC6 ? (MTW < 2 ? MTW : 2) : (MTW < 3 ? MTW : 3);
   bf8 nah[DIST], nal[DIST];
 #pragma unroll
   for (int k = 0; k < DIST; ++k)
@@ -385,29 +402,24 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(ConvArgs a) {
     }
   };
   // five register sets for the weight fragments, rotated with static indices (a run-time index would
-  // send them to scratch): step s uses set s % 5 and refills set (s + 4) % 5, i.e. 4 k-steps of
-  // weight loads (16 KiB per wave in bf16x3) are in flight.  Six sets measured faster per workgroup but
+  // send them to scratch): step s uses set s % 5 and refills set (s + AHEAD) % 5, i.e. AHEAD k-steps of
+  // weight loads (16 KiB per wave in bf16x3 at AHEAD = 4) are in flight.  Six sets measured faster per workgroup but
   // push conv5 past 256 registers (one workgroup per CU: slower).
-  bf8 bh0[NTW], bl0[NTW], bh1[NTW], bl1[NTW], bh2[NTW], bl2[NTW], bh3[NTW], bl3[NTW], bh4[NTW], bl4[NTW];
-  load_b(0, bh0, bl0);
-  load_b(1, bh1, bl1);
-  load_b(2, bh2, bl2);
-  load_b(3, bh3, bl3);
+  bf8 bh[5][NTW], bl[5][NTW];
+  using std::integral_constant;
+  static_for<AHEAD>([&](auto I) { load_b(decltype(I)::value, bh[decltype(I)::value], bl[decltype(I)::value]); });
   static_assert(NSTEP >= 9 && NSTEP % 5 != 0, "NSTEP");  // the last k-step is one of the tail calls below
   constexpr int TAIL = NSTEP % 5;
-  using std::integral_constant;
   int step = 0;
-  for (; step + 5 <= NSTEP; step += 5) {
-    do_step(integral_constant<bool, false>{}, step, bh0, bl0, bh4, bl4);
-    do_step(integral_constant<bool, false>{}, step + 1, bh1, bl1, bh0, bl0);
-    do_step(integral_constant<bool, false>{}, step + 2, bh2, bl2, bh1, bl1);
-    do_step(integral_constant<bool, false>{}, step + 3, bh3, bl3, bh2, bl2);
-    do_step(integral_constant<bool, false>{}, step + 4, bh4, bl4, bh3, bl3);
-  }
-  if (TAIL >= 1) do_step(integral_constant<bool, TAIL == 1>{}, step, bh0, bl0, bh4, bl4);
-  if (TAIL >= 2) do_step(integral_constant<bool, TAIL == 2>{}, step + 1, bh1, bl1, bh0, bl0);
-  if (TAIL >= 3) do_step(integral_constant<bool, TAIL == 3>{}, step + 2, bh2, bl2, bh1, bl1);
-  if (TAIL >= 4) do_step(integral_constant<bool, TAIL == 4>{}, step + 3, bh3, bl3, bh2, bl2);
+  for (; step + 5 <= NSTEP; step += 5)
+    static_for<5>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      do_step(integral_constant<bool, false>{}, step + i, bh[i], bl[i], bh[(i + AHEAD) % 5], bl[(i + AHEAD) % 5]);
+    });
+  static_for<TAIL>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    do_step(integral_constant<bool, i == TAIL - 1>{}, step + i, bh[i], bl[i], bh[(i + AHEAD) % 5], bl[(i + AHEAD) % 5]);
+  });
 
   // ---- epilogue ----------------------------------------------------------------------------------
   // C/D map: acc[k][j][r] = out[patch p0][pixel 16 (wm + WM k) + 4 g + r][channel co_w + 16 j + r16]
@@ -574,13 +586,6 @@ __device__ inline bf8 tr_frag(uint32_t a_lo, uint32_t a_hi) {
   return __builtin_bit_cast(bf8, v);
 }
 
-template <int N, class F>
-__device__ inline void static_for(F &&f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 // slice (1-D grid; id -> (slice, channel group) mapping below).
 // One workgroup (4 waves) = all 9 taps x WG_NCO output channels x NCI input channels of one patch
 // slice; blockIdx.x selects the slice, blockIdx.y the (ci group, co group).
@@ -1368,10 +1373,10 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
   static const char *force = getenv("CRW_CONV_NW");  // diagnostics (tools/probe_conv.py): force 4 or 8 waves
   if (force && force[0] == '4') return launch_conv_nw<SPLIT, CIN, COUT, MODE, 4>(a, s);
   if (force && force[0] == '8') return launch_conv_nw<SPLIT, CIN, COUT, MODE, 8>(a, s);
-  // in-step A/B (tools/ab_kernels.py, CRW_CONV_NW): hi/lo pairs run best with 8 waves except at 32 output channels
-  // (conv3 backward-data, where 8 waves leave a wave 2 of the 7 row tiles: 4 waves are 6-9 % faster); 64 output channels
-  // measured the same either way or box-dependent
-  return launch_conv_nw<SPLIT, CIN, COUT, MODE, (SPLIT == 3 && COUT != 32 ? 8 : 4)>(a, s);
+  // in-step A/B (tools/ab_kernels.py, CRW_CONV_NW): hi/lo pairs run best with 8 waves.  (At 32 output channels -- conv3
+  // backward-data, where 8 waves leave a wave 2 of the 7 row tiles -- 4 waves were 6-9 % faster until the 8-wave kernel got its
+  // third workgroup per CU, see conv_waves_per_simd: 265 -> 259 us.)
+  return launch_conv_nw<SPLIT, CIN, COUT, MODE, (SPLIT == 3 ? 8 : 4)>(a, s);
 }
 
 // input channels per workgroup (one 16-channel tile per wave)
