@@ -407,6 +407,25 @@ struct X6StagerR {
   }
 };
 
+// all-lanes max / sum over the 16 lanes of a DPP row (lanes with equal lane >> 4): four rotate-and-combine steps on the VALU
+// (a __shfl_xor butterfly is four LDS round trips per value)
+template <int CTRL>
+__device__ inline float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float row16_max(float x) {
+  x = fmaxf(x, dpp_f<0x128>(x));  // row_ror:8
+  x = fmaxf(x, dpp_f<0x124>(x));  // row_ror:4
+  x = fmaxf(x, dpp_f<0x122>(x));  // row_ror:2
+  return fmaxf(x, dpp_f<0x121>(x));  // row_ror:1
+}
+__device__ inline float row16_sum(float x) {
+  x += dpp_f<0x128>(x);
+  x += dpp_f<0x124>(x);
+  x += dpp_f<0x122>(x);
+  return x + dpp_f<0x121>(x);
+}
+
 constexpr int AT = 128, ATLD = AT + 4;  // affinity tile and the row stride of its LDS image (16-byte aligned rows; the accumulator writes are conflict-free)
 
 // A[b,t] tile = ehat[b,t][m0..] ehat[b,t+1][n0..]^T / tau, plus (optional) the tile's partial softmax statistics:
@@ -477,7 +496,7 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
   }
   // ---- epilogue: the tile goes to global memory through an LDS image (row-contiguous 16-byte stores), its partial softmax
   // statistics come straight from the accumulators: per wave a row's (max, sum exp) over the wave's 64 columns is an
-  // in-register reduction over j plus a 16-lane butterfly, a column's over the wave's 64 rows one over (i, r) plus the 4 lane
+  // in-register reduction over j plus a 16-lane DPP rotate-reduce, a column's over the wave's 64 rows one over (i, r) plus the 4 lane
   // groups; the two waves that share a row (column) range meet in LDS.  (Walking the LDS image row by row and column by column
   // with one thread each -- the first version -- cost four times the MFMA time of the tile.)
   float v[4][4][4];
@@ -511,13 +530,11 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
         float m = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) m = cok[j] ? fmaxf(m, v[i][j][r]) : m;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        m = row16_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum += cok[j] ? expf(v[i][j][r] - m) : 0.f;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        sum = row16_sum(sum);
         if (r16 == 0) {
           float *dst = rpart + ((wn >> 6) * AT + wm + 16 * i + 4 * g + r) * 2;
           dst[0] = m;
