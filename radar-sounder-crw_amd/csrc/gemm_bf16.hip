@@ -114,9 +114,9 @@ struct BfOperand {
 template <int TB_>
 struct Cfg;
 template <>
-struct Cfg<128> { static constexpr int TB = 128, WAVES = 4, WN = 2, FM = 4, FN = 4; };
+struct Cfg<128> { static constexpr int WAVES = 4, WN = 2, FM = 4, FN = 4; };
 template <>
-struct Cfg<256> { static constexpr int TB = 256, WAVES = 8, WN = 4, FM = 8, FN = 4; };
+struct Cfg<256> { static constexpr int WAVES = 8, WN = 4, FM = 8, FN = 4; };
 
 // Stages of the LDS-DMA ring: two everywhere.  At 128 x 128 / plain bf16 a stage is 32 KiB, which leaves room for TWO
 // workgroups per CU; measured at n = 4096 that beats one workgroup with a 4-stage ring (800 vs 605 TFLOP/s).

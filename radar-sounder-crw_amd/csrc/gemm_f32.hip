@@ -430,24 +430,27 @@ constexpr int AT = 128, ATLD = AT + 4;  // affinity tile and the row stride of i
 
 // A[b,t] tile = ehat[b,t][m0..] ehat[b,t+1][n0..]^T / tau, plus (optional) the tile's partial softmax statistics:
 // per row the (max, sum exp) over the tile's valid columns -> rpart[mat][tn][row], per column over its rows -> cpart[mat][tm][col]
-template <bool X6>  // X6: products on the bf16 matrix cores in three-term splits (C % 32 == 0), else fp32 MFMA
+// TS = rows and columns of the tile: 128, or 64 for matrices that fit one 64 x 64 tile (N <= 64: a quarter of the MFMA and
+// statistics work of a 128-tile that is three quarters empty -- the kernel is pure latency there, one workgroup per CU)
+template <bool X6, int TS = 128>  // X6: products on the bf16 matrix cores in three-term splits (C % 32 == 0), else fp32 MFMA
 __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restrict__ ehat, int T, int N, int C, float tau,
                                                             float *__restrict__ A, float *__restrict__ part, int tiles,
                                                             float *__restrict__ direct) {
-  constexpr int LD = AT + 16;
+  constexpr int LD = TS + 16, TW = TS / 32, HW = TS / 2, TSLD = TS + 4;  // tiles per wave and dimension, wave quadrant, image stride
+  static_assert(!X6 || TS == 128, "the bf16 form is built for 128-tiles");
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   float *As = lds_f, *Bs = lds_f + BK * LD, *tile = lds_f;  // the output tile reuses the operand space
-  const int tm = blockIdx.x / tiles, tn = blockIdx.x % tiles, m0 = tm * AT, n0 = tn * AT;
+  const int tm = blockIdx.x / tiles, tn = blockIdx.x % tiles, m0 = tm * TS, n0 = tn * TS;
   const long amat = blockIdx.y;                    // caller order: b * (T - 1) + t
   const long b = amat / (T - 1), t = amat % (T - 1);
   const float *E0 = ehat + (b * T + t) * (long)N * C, *E1 = E0 + (long)N * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  f32x4 acc[4][4];
+  const int wm = (wave >> 1) * HW, wn = (wave & 1) * HW;
+  f32x4 acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (X6) {
     constexpr int PL = AT * 64;  // one bf16 plane of a 128-row operand, 32 deep
     char *Ap = reinterpret_cast<char *>(lds_f), *Bp = Ap + 3 * PL;
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
       __syncthreads();
       sa0.load(E0, C, m0, min(kt + 2, nk - 1) * X6K, N, C, tid);  // unconditional (clamped): unused past the end
       sb0.load(E1, C, n0, min(kt + 2, nk - 1) * X6K, N, C, tid);
-      x6_block<4, 4, PL, PL>(Ap, Bp, wm, wn, lane, acc);
+      x6_block<TW, TW, PL, PL>(Ap, Bp, wm, wn, lane, acc);
       __syncthreads();
       if (kt + 1 < nk) {
         sa1.store<PL>(Ap, tid);
@@ -473,24 +476,24 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
         __syncthreads();
         sa1.load(E0, C, m0, min(kt + 3, nk - 1) * X6K, N, C, tid);
         sb1.load(E1, C, n0, min(kt + 3, nk - 1) * X6K, N, C, tid);
-        x6_block<4, 4, PL, PL>(Ap, Bp, wm, wn, lane, acc);
+        x6_block<TW, TW, PL, PL>(Ap, Bp, wm, wn, lane, acc);
         __syncthreads();
       }
     }
   } else {
-  BoundStager<AT> sa, sb;
+  BoundStager<TS> sa, sb;
   const int nk = (C + BK - 1) / BK;
   sa.load(E0, C, m0, 0, true, N, C, tid);
   sb.load(E1, C, n0, 0, true, N, C, tid);
   for (int kt = 0; kt < nk; ++kt) {
-    sa.store<LD>(As, true, tid);
-    sb.store<LD>(Bs, true, tid);
+    sa.template store<LD>(As, true, tid);
+    sb.template store<LD>(Bs, true, tid);
     __syncthreads();
     if (kt + 1 < nk) {
       sa.load(E0, C, m0, (kt + 1) * BK, true, N, C, tid);
       sb.load(E1, C, n0, (kt + 1) * BK, true, N, C, tid);
     }
-    mfma_block<4, 4, LD, LD>(As, Bs, wm, wn, lane, acc);
+    mfma_block<TW, TW, LD, LD>(As, Bs, wm, wn, lane, acc);
     __syncthreads();
   }
   }
@@ -499,67 +502,67 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
   // in-register reduction over j plus a 16-lane DPP rotate-reduce, a column's over the wave's 64 rows one over (i, r) plus the 4 lane
   // groups; the two waves that share a row (column) range meet in LDS.  (Walking the LDS image row by row and column by column
   // with one thread each -- the first version -- cost four times the MFMA time of the tile.)
-  float v[4][4][4];
+  float v[TW][TW][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[i][j][r] = acc[i][j][r] / tau;
   const int g = lane >> 4, r16 = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tile[(wm + 16 * i + 4 * g + r) * ATLD + wn + 16 * j + r16] = v[i][j][r];
-  float *rpart = tile + AT * ATLD, *cpart = rpart + 2 * AT * 2;  // [2 column halves][128 rows][m, s], [2 row halves][128 cols][m, s]
+      for (int r = 0; r < 4; ++r) tile[(wm + 16 * i + 4 * g + r) * TSLD + wn + 16 * j + r16] = v[i][j][r];
+  float *rpart = tile + TS * TSLD, *cpart = rpart + 2 * TS * 2;  // [2 column halves][128 rows][m, s], [2 row halves][128 cols][m, s]
   if (part || direct) {
-    bool cok[4], rok[4][4];
+    bool cok[TW], rok[TW][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cok[j] = n0 + wn + 16 * j + r16 < N;
+    for (int j = 0; j < TW; ++j) cok[j] = n0 + wn + 16 * j + r16 < N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) rok[i][r] = m0 + wm + 16 * i + 4 * g + r < N;
     // rows: over this wave's columns
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float m = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m = cok[j] ? fmaxf(m, v[i][j][r]) : m;
+        for (int j = 0; j < TW; ++j) m = cok[j] ? fmaxf(m, v[i][j][r]) : m;
         m = row16_max(m);
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sum += cok[j] ? expf(v[i][j][r] - m) : 0.f;
+        for (int j = 0; j < TW; ++j) sum += cok[j] ? expf(v[i][j][r] - m) : 0.f;
         sum = row16_sum(sum);
         if (r16 == 0) {
-          float *dst = rpart + ((wn >> 6) * AT + wm + 16 * i + 4 * g + r) * 2;
+          float *dst = rpart + ((wave & 1) * TS + wm + 16 * i + 4 * g + r) * 2;
           dst[0] = m;
           dst[1] = sum;
         }
       }
     // columns: over this wave's rows
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TW; ++j) {
       float m = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) m = rok[i][r] ? fmaxf(m, v[i][j][r]) : m;
       m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
       float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum += rok[i][r] ? expf(v[i][j][r] - m) : 0.f;
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
       if (g == 0) {
-        float *dst = cpart + ((wm >> 6) * AT + wn + 16 * j + r16) * 2;
+        float *dst = cpart + ((wave >> 1) * TS + wn + 16 * j + r16) * 2;
         dst[0] = m;
         dst[1] = sum;
       }
@@ -568,23 +571,24 @@ __global__ __launch_bounds__(256) void affinity_tile_kernel(const float *__restr
   __syncthreads();
   float *Ab = A + amat * (long)N * N;
   if ((N & 3) == 0) {  // a wave writes 512 contiguous bytes of two rows per instruction
-    for (int e = tid; e < AT * AT / 4; e += 256) {
-      const int r = e >> 5, c = 4 * (e & 31);
+    for (int e = tid; e < TS * TS / 4; e += 256) {
+      const int r = e / (TS / 4), c = 4 * (e % (TS / 4));
       if (m0 + r < N && n0 + c < N)
-        *reinterpret_cast<float4 *>(Ab + (long)(m0 + r) * N + n0 + c) = *reinterpret_cast<const float4 *>(tile + r * ATLD + c);
+        *reinterpret_cast<float4 *>(Ab + (long)(m0 + r) * N + n0 + c) = *reinterpret_cast<const float4 *>(tile + r * TSLD + c);
     }
   } else {
-    for (int e = tid; e < AT * AT; e += 256) {
-      const int r = e >> 7, c = e & 127;
-      if (m0 + r < N && n0 + c < N) Ab[(long)(m0 + r) * N + n0 + c] = tile[r * ATLD + c];
+    for (int e = tid; e < TS * TS; e += 256) {
+      const int r = e / TS, c = e % TS;
+      if (m0 + r < N && n0 + c < N) Ab[(long)(m0 + r) * N + n0 + c] = tile[r * TSLD + c];
     }
   }
   if (!part && !direct) return;
   // threads 0..127: one tile row each; threads 128..255: one tile column each: merge the two half-tile partials
-  const int idx = tid & 127;
-  const bool rows = tid < 128;
+  if (tid >= 2 * TS) return;
+  const int idx = tid % TS;
+  const bool rows = tid < TS;
   const float *pp = (rows ? rpart : cpart) + idx * 2;
-  const float ma = pp[0], sa = pp[1], mb = pp[AT * 2], sb = pp[AT * 2 + 1];
+  const float ma = pp[0], sa = pp[1], mb = pp[TS * 2], sb = pp[TS * 2 + 1];
   const float m = fmaxf(ma, mb);
   const float sum = (sa > 0.f ? sa * expf(ma - m) : 0.f) + (sb > 0.f ? sb * expf(mb - m) : 0.f);
   const int gi = (rows ? m0 : n0) + idx;
@@ -782,6 +786,12 @@ int launch_affinity_tiles(const float *ehat, int B, int T, int N, int C, float t
     attr = true;
   }
   const bool single = tiles == 1;
+  if (N <= 64) {  // one 64 x 64 tile per matrix
+    const size_t lds64 = sizeof(float) * (size_t)(64 * 68 + 2 * 2 * 64 * 2);  // tile image + half-tile partials (> the operand tiles)
+    hipLaunchKernelGGL((affinity_tile_kernel<false, 64>), dim3(1, nmat), dim3(256), lds64, s, ehat, T, N, C, tau, A, nullptr, 1,
+                       stats);
+    return check_launch();
+  }
   if (affinity_on_bf16(N, C))
     hipLaunchKernelGGL(affinity_tile_kernel<true>, dim3(tiles * tiles, nmat), dim3(256), lds, s, ehat, T, N, C, tau, A,
                        (stats && !single) ? part : nullptr, tiles, (stats && single) ? stats : nullptr);
