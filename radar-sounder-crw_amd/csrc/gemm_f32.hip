@@ -242,18 +242,43 @@ struct BoundStager {
   static constexpr int NV4 = R * BK / 4, PER = (NV4 + 255) / 256;
   float4 v[PER];
   // kcontig : X[(r0 + r) * ld + k0 + k]   (kmax % 4 == 0)         !kcontig: X[(k0 + k) * ld + r0 + r]   (rmax % 4 == 0)
+  // AL = false: no alignment or multiple-of-4 assumption (element loads, bounds per element): operands whose leading dimension is
+  // not a multiple of 4, e.g. dA at the default 63 nodes
+  template <bool AL = true>
   __device__ inline void load(const float *__restrict__ X, long ld, int r0, int k0, bool kcontig, int rmax, int kmax, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = min(tid + i * 256, NV4 - 1);
       if (kcontig) {
         const int r = e >> 2, k = k0 + 4 * (e & 3);
-        const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(r0 + r, rmax - 1) * ld + min(k, kmax - 4));
-        v[i] = k < kmax ? t : float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (AL) {
+          const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(r0 + r, rmax - 1) * ld + min(k, kmax - 4));
+          v[i] = k < kmax ? t : float4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          const float *row = X + (long)min(r0 + r, rmax - 1) * ld;
+          float t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float x = row[min(k + u, kmax - 1)];  // unconditional, clamped
+            t[u] = k + u < kmax ? x : 0.f;
+          }
+          v[i] = float4{t[0], t[1], t[2], t[3]};
+        }
       } else {
         const int k = k0 + e / (R / 4), r = r0 + 4 * (e % (R / 4));
-        const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(k, kmax - 1) * ld + min(r, rmax - 4));
-        v[i] = (k < kmax && r < rmax) ? t : float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (AL) {
+          const float4 t = *reinterpret_cast<const float4 *>(X + (long)min(k, kmax - 1) * ld + min(r, rmax - 4));
+          v[i] = (k < kmax && r < rmax) ? t : float4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          const float *row = X + (long)min(k, kmax - 1) * ld;
+          float t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float x = row[min(r + u, rmax - 1)];
+            t[u] = (k < kmax && r + u < rmax) ? x : 0.f;
+          }
+          v[i] = float4{t[0], t[1], t[2], t[3]};
+        }
       }
     }
   }
@@ -620,23 +645,24 @@ __global__ __launch_bounds__(256) void affinity_stats_merge_kernel(const float *
   stats[((2 * which + 1) * nmat + mat) * N + n] = s;
 }
 
-// dehat[b,t] tile (128 rows x C) = (dA[b,t] ehat[b,t+1] + dA[b,t-1]^T ehat[b,t-1]) / tau;  N % 4 == 0, C = 32 * TN2 * 2
-template <int TN>  // 16-wide column tiles per wave: C = 32 * TN
+// dehat[b,t] tile (RM rows x C) = (dA[b,t] ehat[b,t+1] + dA[b,t-1]^T ehat[b,t-1]) / tau;  C = 32 * TN; RM = 128, or 64 for matrices of
+// at most 64 nodes (half the MFMA work of a half-empty 128-row tile: the launch is pure latency there); AL = false: N % 4 != 0
+template <int TN, int RM = 128, bool AL = true>  // TN: 16-wide column tiles per wave
 __global__ __launch_bounds__(256) void affinity_bwd_tile_kernel(const float *__restrict__ dA, const float *__restrict__ ehat,
                                                                 int T, int N, float tau, float *__restrict__ dehat) {
-  constexpr int C = 32 * TN, LDA = AT + 16, LDB = C + 16;
+  constexpr int C = 32 * TN, LDA = RM + 16, LDB = C + 16, TM = RM / 32;
   __shared__ __attribute__((aligned(16))) float lds_f[BK * LDA + BK * LDB];
   float *As = lds_f, *Bs = lds_f + BK * LDA;
-  const int m0 = blockIdx.x * AT;
+  const int m0 = blockIdx.x * RM;
   const long bt = blockIdx.y, b = bt / T, t = bt % T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (C / 2);
-  f32x4 acc[4][TN];
+  const int wm = (wave >> 1) * (RM / 2), wn = (wave & 1) * (C / 2);
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  BoundStager<AT> sa;
+  BoundStager<RM> sa;
   BoundStager<C> sb;
   const long NN = (long)N * N, NC = (long)N * C;
   const int nk = (N + BK - 1) / BK;
@@ -646,23 +672,23 @@ __global__ __launch_bounds__(256) void affinity_bwd_tile_kernel(const float *__r
     const float *X = dA + (b * (T - 1) + (prod == 0 ? t : t - 1)) * NN;
     const float *E = ehat + (b * T + (prod == 0 ? t + 1 : t - 1)) * NC;
     const bool akc = prod == 0;
-    sa.load(X, N, m0, 0, akc, N, N, tid);
+    sa.template load<AL>(X, N, m0, 0, akc, N, N, tid);
     sb.load(E, C, 0, 0, false, C, N, tid);
     for (int kt = 0; kt < nk; ++kt) {
       sa.template store<LDA>(As, akc, tid);
       sb.template store<LDB>(Bs, false, tid);
       __syncthreads();
       if (kt + 1 < nk) {
-        sa.load(X, N, m0, (kt + 1) * BK, akc, N, N, tid);
+        sa.template load<AL>(X, N, m0, (kt + 1) * BK, akc, N, N, tid);
         sb.load(E, C, 0, (kt + 1) * BK, false, C, N, tid);
       }
-      mfma_block<4, TN, LDA, LDB>(As, Bs, wm, wn, lane, acc);
+      mfma_block<TM, TN, LDA, LDB>(As, Bs, wm, wn, lane, acc);
       __syncthreads();
     }
   }
   float *D = dehat + bt * NC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -807,8 +833,22 @@ int launch_affinity_tiles(const float *ehat, int B, int T, int N, int C, float t
 
 int launch_affinity_bwd_tiles(const float *dA, const float *ehat, int B, int T, int N, int C, float tau, float *dehat,
                               hipStream_t s) {
-  if (N % 4 || N < 4) return CRW_EINVAL;
+  if (N < 1) return CRW_EINVAL;
   const dim3 grid((N + AT - 1) / AT, B * T);
+  if (N <= 64 || (N & 3)) {  // one 64-row tile per matrix / node counts that are not a multiple of 4 (element loads of dA)
+#define CRW_AFB(TNV)                                                                                                            \
+  if (N <= 64 && !(N & 3)) hipLaunchKernelGGL((affinity_bwd_tile_kernel<TNV, 64, true>), dim3(1, B * T), dim3(256), 0, s, dA, ehat, T, N, tau, dehat); \
+  else if (N <= 64) hipLaunchKernelGGL((affinity_bwd_tile_kernel<TNV, 64, false>), dim3(1, B * T), dim3(256), 0, s, dA, ehat, T, N, tau, dehat);       \
+  else hipLaunchKernelGGL((affinity_bwd_tile_kernel<TNV, 128, false>), grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat);
+    switch (C) {
+      case 32: CRW_AFB(1) break;
+      case 64: CRW_AFB(2) break;
+      case 128: CRW_AFB(4) break;
+      default: return CRW_EINVAL;
+    }
+#undef CRW_AFB
+    return check_launch();
+  }
   if (C == 128 && affinity_on_bf16(N, C)) {
     hipLaunchKernelGGL(affinity_bwd_x6_kernel, grid, dim3(256), 0, s, dA, ehat, T, N, tau, dehat);
     return check_launch();

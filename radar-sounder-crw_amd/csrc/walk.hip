@@ -398,7 +398,7 @@ int crw_affinity_bwd(const float *dA, const float *ehat, const float *norm, int 
   if (!dA || !ehat || !norm || !dehat_ws || !demb || bad_shape(B, T, N) || C < 1 || !(tau > 0.f)) return CRW_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long NC = (long)N * C, NN = (long)N * N;
-  if (N % 4 == 0 && (C == 32 || C == 64 || C == 128)) {  // 128-row fp32-MFMA tiles
+  if (C == 32 || C == 64 || C == 128) {  // fp32-MFMA / bf16-split tiles (any node count)
     CRW_TRY(launch_affinity_bwd_tiles(dA, ehat, B, T, N, C, tau, dehat_ws, s));
     const long rows_ = (long)B * T * N;
     hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)((rows_ + 3) / 4)), dim3(256), 0, s, dehat_ws, ehat, norm, rows_, C, demb);
