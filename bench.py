@@ -392,7 +392,8 @@ def main():
     net = crw_model.CRW(enc, TAU, False).to(device)
     net.train(True)
     bucket = crw_dist.FlatGradBucket(net.parameters(), lazy=True)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    import optim as crw_optim
+    opt = crw_optim.FlatAdam(bucket, lr=1e-3)  # torch.optim.Adam's update, one launch over the flat parameter buffer
     seq = make_batch(rank, device)
     B, T, N = seq.shape[:3]
     cols_per_step = B * (T * (PATCH[1] - OVERLAP[1]) + OVERLAP[1])

@@ -47,7 +47,7 @@ extern "C" {
 typedef void *crw_stream_t;
 
 /* library / build info ------------------------------------------------------------------- */
-int crw_abi_version(void);          /* bumps when a signature changes                       */
+int crw_abi_version(void);          /* bumps when a signature changes or an entry point is added (4) */
 const char *crw_build_arch(void);   /* "gfx950"                                             */
 int crw_last_hip_error(void);       /* last hipError_t seen by this thread (0 = none)       */
 
@@ -118,6 +118,13 @@ int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_str
  * are added in a fixed order (a library GEMM runs this M=N=128, K=P shape on 16 workgroups).  P % 128 == 0. */
 size_t crw_linear128_wgrad_ws_bytes(int P);
 int crw_linear128_wgrad(const float *dy, const float *x, float *dw, int P, void *ws, size_t ws_bytes, crw_stream_t stream);
+
+/* One Adam step (torch.optim.Adam defaults: no weight decay, no amsgrad -- the reference's optimizer, scripts/train.py:54,69) on a
+ * flat fp32 parameter buffer p[n] with gradient g[n] and moment buffers m[n], v[n] (all 16-byte aligned); step = 1, 2, ...
+ * Operation for operation the arithmetic of torch's default implementation; the host side keeps the module's parameters as views
+ * of p (radar-sounder-crw_amd/optim.py) and the gradients as views of g (dist.FlatGradBucket). */
+int crw_adam_step(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2, float eps, int step,
+                  crw_stream_t stream);
 
 /* X [batch,n,n] (n multiple of 32, zero padded): C = op(A) * op(B) (+ C if beta), fp32 MFMA. */
 int crw_gemm_f32(const float *A, const float *B, float *C, int n, int batch, int transA, int transB,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
     "crw_linear128_wgrad_ws_bytes": (_c_sz, [_c_int]),
     "crw_linear128_wgrad": (_c_int, [_p, _p, _p, _c_int, _p, _c_sz, _p]),
+    "crw_adam_step": (_c_int, [_p, _p, _p, _p, ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                               _c_int, _p]),
     "crw_gemm_f32": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p]),
     "crw_enc_pack_weights": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "crw_enc_pack_input": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
@@ -299,6 +301,12 @@ def linear128_wgrad(dy, x):
     _check(lib().crw_linear128_wgrad(_dev(dy.contiguous(), "dy"), _dev(x.contiguous(), "x"), _dev(dw, "dw"), P,
                                      ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()), "crw_linear128_wgrad")
     return dw
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One Adam step in place on the flat fp32 buffers p (parameters), m, v with the flat gradient g (torch.optim.Adam defaults)."""
+    _check(lib().crw_adam_step(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), p.numel(), float(lr), float(beta1),
+                               float(beta2), float(eps), int(step), _stream()), "crw_adam_step")
 
 
 def enc_pack_input_map(x, split):

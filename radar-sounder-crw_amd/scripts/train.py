@@ -92,8 +92,12 @@ def main(args, on_step=None):
         # the item cut is a strided view of the radargram (src/dataset.py:19-39): with the radargram resident in
         # HBM a batch is one gather kernel instead of a CPU unfold + 16 MB host-to-device copy per step
         base.T = base.T.to(device)
-    optimizer = Adam(model.parameters(), lr=args.lr, fused=True)  # one kernel for all parameters (same update rule)
     bucket = crw_dist.FlatGradBucket(model.parameters(), lazy=True)
+    if device.type == "cuda":  # torch.optim.Adam's update (the reference's optimizer) as one launch over flat buffers
+        import optim as crw_optim
+        optimizer = crw_optim.FlatAdam(bucket, lr=args.lr)
+    else:
+        optimizer = Adam(model.parameters(), lr=args.lr)
     model.train(True)
     loss_tot, nsteps = [], 0
     for epoch in range(args.epochs):

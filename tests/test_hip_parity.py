@@ -886,6 +886,37 @@ def test_flat_gradient_all_reduce_on_rccl(hip, tmp_path):
         tdist.destroy_process_group()
 
 
+def test_flat_adam_matches_torch_adam(hip):
+    """optim.FlatAdam (one crw_adam_step launch over the flat parameter / gradient buffers) against torch.optim.Adam with its
+    defaults -- the reference's optimizer (scripts/train.py:54,69) -- over 6 steps of random gradients: same parameters to fp32
+    rounding, the module's parameters stay views of the flat buffer, and a second module driven by torch's Adam ends up equal."""
+    import dist as crw_dist
+    import optim as crw_optim
+    torch.manual_seed(5)
+    a = torch.nn.Sequential(torch.nn.Conv2d(1, 3, 3), torch.nn.Linear(7, 5), torch.nn.Linear(5, 130)).cuda()
+    b = torch.nn.Sequential(torch.nn.Conv2d(1, 3, 3), torch.nn.Linear(7, 5), torch.nn.Linear(5, 130)).cuda()
+    b.load_state_dict(a.state_dict())
+    bucket = crw_dist.FlatGradBucket(a.parameters(), lazy=False)
+    fa = crw_optim.FlatAdam(bucket, lr=1e-2)
+    ta = torch.optim.Adam(b.parameters(), lr=1e-2)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for step in range(6):
+        scale = 10.0 ** (step - 3)  # gradients over six orders of magnitude
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            gr = torch.randn(pa.shape, device="cuda", generator=g) * scale
+            pa.grad.copy_(gr)
+            pb.grad = gr.clone()
+        fa.step()
+        ta.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            torch.testing.assert_close(pa.data, pb.data, rtol=2e-6, atol=1e-8)  # an update is ~lr = 1e-2: a few of its ulps
+    o = 0
+    for pa in a.parameters():  # still views of the flat buffer, in order
+        assert pa.data.data_ptr() == fa.flat.data_ptr() + 4 * o
+        o += pa.numel()
+    assert set(a.state_dict()) == set(b.state_dict())
+
+
 def test_bench_two_rank_control_flow_rehearsal(hip):
     """bench.py's N > 1 path (launcher env, sharded radargrams, flat-gradient exchange every step, barrier + max-over-ranks timing,
     one JSON line from rank 0) run as TWO ranks -- on this box's one GPU over gloo (CRW_DIST_REHEARSAL: RCCL refuses two ranks on

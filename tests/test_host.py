@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in crw_hip.h but not exported"
     assert declared == set(crw_hip.SIGNATURES), declared ^ set(crw_hip.SIGNATURES)
     lib = crw_hip.lib()
-    assert lib.crw_abi_version() == 3 and lib.crw_build_arch() == b"gfx950"
+    assert lib.crw_abi_version() == 4 and lib.crw_build_arch() == b"gfx950"
     # pure host-side geometry queries
     assert [lib.crw_padded_nodes(n, 0) for n in (1, 7, 63, 64, 65, 128, 129, 497, 1024, 1025, 4096)] == \
         [32, 32, 64, 64, 96, 128, 192, 512, 1024, 1152, 4096]
