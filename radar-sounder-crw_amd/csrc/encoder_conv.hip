@@ -970,9 +970,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_wgrad_kernel(WgradArg
 //     and 16-pitch X images, source-side swizzles, counted vmcnt + raw barrier, no staging registers): parity-green, 1123 us
 //     against 1073 us for this register-staged form (conv5, P = 16128; in-step 1205 vs 1070) -- 3.6 DMA issues and ~150
 //     address VALU per wave and k-step cost more than the staging they replace.  What the staging costs here: CRW_WGRAD_DIAG.
-//   * Rows of a k-step are dealt to the lane groups by parity (half-wave 0: even rows, half-wave 1: odd rows): on the
-//     2C+16 row stride eight same-parity rows start in eight different bank octets (consecutive rows collide 2-way).
+//   * LDS planes on a 2C+32 row stride, fragment rows in stream order: eight consecutive dY rows start in eight different
+//     bank octets; the X reads (eight pixels that usually straddle an image-row end) cost 1.6 LDS cycles each instead of the 2.0
+//     of the first version (rows dealt by parity on a 2C+16 stride) -- worth 0.5-1 % of the kernel.
 constexpr int W2_NCO = 128, W2_NCI = 64, W2_NW = 8, W2_KROWS = 32;
+template <int C>
+constexpr int w2_stride() { return 2 * C + 32; }  // LDS row stride of the streamed kernel's planes (see the fragment-row order below)
 
 // DIAG (timing-only diagnostic builds of the conv5 shape, CRW_WGRAD_DIAG=1..5; results are wrong): 1 = no barrier in the k-loop,
 // 2 = no staging (no global loads, no LDS stores), 3 = both, 4 = global loads but no LDS stores, 5 = LDS stores but no global
@@ -980,8 +983,8 @@ constexpr int W2_NCO = 128, W2_NCI = 64, W2_NW = 8, W2_KROWS = 32;
 template <int SPLIT, int CIN, int COUT, int DIAG = 0>
 __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
   constexpr int NCO = W2_NCO, NCI = W2_NCI, NTH = W2_NW * 64, NPL = (SPLIT == 3) ? 2 : 1;
-  constexpr int XS = row_stride<NCI>(), XPL = NPAD * XS, XSLOT = NPL * XPL;     // X: 12x12 padded image per plane
-  constexpr int YS = row_stride<NCO>(), YPL = W2_KROWS * YS, YSLOT = NPL * YPL; // dY: 32 rows per plane
+  constexpr int XS = w2_stride<NCI>(), XPL = NPAD * XS, XSLOT = NPL * XPL;     // X: 12x12 padded image per plane
+  constexpr int YS = w2_stride<NCO>(), YPL = W2_KROWS * YS, YSLOT = NPL * YPL; // dY: 32 rows per plane
   constexpr int NCOW = 4, WCI = 4;                                              // wave tile: 4 co tiles x 1 ci tile
   static_assert(COUT == NCO && CIN % NCI == 0, "tiling");
   constexpr int NGRP = CIN / NCI;
@@ -1095,8 +1098,11 @@ __global__ __launch_bounds__(W2_NW * 64, 2) void conv3x3_wgrad2_kernel(WgradArgs
   const uint32_t xs_a = (uint32_t)(uintptr_t)(lds_cp)xs, ys_a = (uint32_t)(uintptr_t)(lds_cp)ys;
   const int t16 = lane & 15, q4 = t16 >> 2, pq = t16 & 3;
   const uint32_t lane_col = 8 * (pq & 1) + 16 * (pq >> 1);
-  // parity order: lane group g, fragment row q4 -> k-step row 2 (4 (g & 1) + q4) + (g >> 1)  (+16 for the second read)
-  const int r_lo = 2 * (4 * (g & 1) + q4) + (g >> 1), r_hi = r_lo + 16;
+  // fragment row order: lane group g, fragment row q4 -> k-step row 4 g + q4  (+16 for the second read).  On the 2C+32 row stride
+  // eight consecutive dY rows start in eight different bank octets (conflict-free), and the eight X pixels of a lane-group pair,
+  // which straddle an image-row end more often than not, cost 1.6 LDS cycles per read on average (bank simulation over the
+  // pixel stream); the parity order on the 2C+16 stride of the first version cost 2.0
+  const int r_lo = 4 * g + q4, r_hi = r_lo + 16;
   const uint32_t ya_lo0 = ys_a + r_lo * YS + lane_col + 2 * co0w, ya_hi0 = ys_a + r_hi * YS + lane_col + 2 * co0w;
   auto x_addr = [&](int G) {  // tap-(0,0) source pixel of stream pixel G in its patch slot
     const int Gc = min(G, npx - 1);  // rows past the stream multiply zero dY rows: any valid address
@@ -1423,7 +1429,7 @@ int launch_wgrad_map(const WgradArgs &a, int nblk, hipStream_t s) {
 template <int SPLIT, int CIN, int COUT, int DIAG = 0>
 int launch_wgrad2(const WgradArgs &a, int nslice, hipStream_t s) {
   constexpr int NPL = SPLIT == 3 ? 2 : 1;
-  const size_t lds = (size_t)2 * NPL * (NPAD * row_stride<W2_NCI>() + W2_KROWS * row_stride<W2_NCO>()) + 2 * 4 * W2_NCO;
+  const size_t lds = (size_t)2 * NPL * (NPAD * w2_stride<W2_NCI>() + W2_KROWS * w2_stride<W2_NCO>()) + 2 * 4 * W2_NCO;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void *)conv3x3_wgrad2_kernel<SPLIT, CIN, COUT, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize,
