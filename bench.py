@@ -542,6 +542,21 @@ def main():
                             "launch_us": bms * 1e3, "shape": "n=4096 batch=3",
                             "note": "MFMA flops executed" + (" (3 bf16 MFMAs per product: useful flops = 1/3)"
                                                              if split == 3 else "")}
+        if world == 1 and args.workload == "dense":
+            # the same step with the opt-in hi/lo-pair chain arithmetic (CRW.chain = CRW_CHAIN_BF16X3: fp32-grade products at a third
+            # of the bf16 rate instead of fp32 MFMA): at N = 497 the chain GEMMs are 11 % of the default step
+            net.chain = crw_hip.CHAIN_BF16X3
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l3 = step()
+            torch.cuda.synchronize()
+            ms3 = (time.perf_counter() - t1) / args.steps * 1e3
+            out["option_chain_bf16x3"] = {"ms_per_step": ms3, "value": cols_per_step / (ms3 * 1e-3), "loss_after_these_steps": l3.item(),
+                                          "note": "same workload, training continued with CRW.chain = CRW_CHAIN_BF16X3 (opt-in; the "
+                                                  "default stays exact fp32)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
