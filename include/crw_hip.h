@@ -34,6 +34,11 @@
 extern "C" {
 #endif
 
+/* Bumps when a signature changes or an entry point is added.  The ONE place the number is written: crw_abi_version() returns
+ * it, the ctypes binding (crw_hip.ABI_VERSION) parses it from this header, and __graft_entry__.build() / the host tests compare
+ * the two. */
+#define CRW_ABI_VERSION 5
+
 #define CRW_OK 0
 #define CRW_EINVAL 1     /* bad shape / null pointer / unsupported size            */
 #define CRW_EWORKSPACE 2 /* workspace too small                                     */
@@ -47,7 +52,7 @@ extern "C" {
 typedef void *crw_stream_t;
 
 /* library / build info ------------------------------------------------------------------- */
-int crw_abi_version(void);          /* bumps when a signature changes or an entry point is added (4) */
+int crw_abi_version(void);          /* CRW_ABI_VERSION of the header the library was built with */
 const char *crw_build_arch(void);   /* "gfx950"                                             */
 int crw_last_hip_error(void);       /* last hipError_t seen by this thread (0 = none)       */
 

@@ -12,6 +12,19 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRW_HIP_LIB") or os.path.join(_HERE, "libcrw_hip.so")  # CRW_HIP_LIB: A/B of two builds (tools/)
 
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "crw_hip.h")
+
+
+def _header_abi_version():
+    """CRW_ABI_VERSION as include/crw_hip.h defines it -- the number is written nowhere else."""
+    import re
+    m = re.search(r"^#define\s+CRW_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read(), re.M)
+    if not m:
+        raise RuntimeError(f"no CRW_ABI_VERSION in {HEADER_PATH}")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
 CRW_OK, CRW_EINVAL, CRW_EWORKSPACE, CRW_EHIP = 0, 1, 2, 3
 CHAIN_F32, CHAIN_BF16, CHAIN_BF16X3 = 0, 1, 2
 _ERR = {1: "CRW_EINVAL (bad shape / null pointer / unsupported size)",
@@ -78,6 +91,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        if handle.crw_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} was built for ABI {handle.crw_abi_version()}, include/crw_hip.h says {ABI_VERSION}: "
+                               "stale library -- rebuild with `make -C radar-sounder-crw_amd/csrc`")
         _lib = handle
     return _lib
 

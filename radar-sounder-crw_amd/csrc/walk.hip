@@ -194,7 +194,7 @@ using namespace crw;
 
 extern "C" {
 
-int crw_abi_version(void) { return 4; }
+int crw_abi_version(void) { return CRW_ABI_VERSION; }
 const char *crw_build_arch(void) { return "gfx950"; }
 int crw_last_hip_error(void) { return g_last_hip_error; }
 int crw_padded_nodes(int N, int chain) { return (N < 1 || bad_chain(chain)) ? 0 : chain_padded_nodes(N, chain); }

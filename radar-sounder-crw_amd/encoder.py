@@ -26,7 +26,7 @@ class _HipEncoder(torch.autograd.Function):
     """The whole conv trunk of ``CNN`` on the HIP kernels: fused front end (conv1-ReLU-pool-conv2-ReLU-
     pool), conv3/conv4/conv5 (+ReLU) and the global average pool.  x [P,cin,16,16] fp32 -> [P,128] fp32.
     Saved for backward: the input patches and the bf16 activation planes of conv2..conv5 outputs
-    (the front end is recomputed in its backward kernel)."""
+    and the front end's record (pool1 planes + pooling codes), from which its backward kernel runs without recomputation."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, split):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in crw_hip.h but not exported"
     assert declared == set(crw_hip.SIGNATURES), declared ^ set(crw_hip.SIGNATURES)
     lib = crw_hip.lib()
-    assert lib.crw_abi_version() == 4 and lib.crw_build_arch() == b"gfx950"
+    assert lib.crw_abi_version() == crw_hip.ABI_VERSION and lib.crw_build_arch() == b"gfx950"
     # pure host-side geometry queries
     assert [lib.crw_padded_nodes(n, 0) for n in (1, 7, 63, 64, 65, 128, 129, 497, 1024, 1025, 4096)] == \
         [32, 32, 64, 64, 96, 128, 192, 512, 1024, 1152, 4096]
@@ -34,6 +34,29 @@ def test_library_exports_every_declared_symbol():
     s1, s2 = lib.crw_walk_state_bytes(1, 32, 63, 0), lib.crw_walk_state_bytes(2, 32, 63, 0)
     assert 0 < s1 < s2 <= 2 * s1
     assert lib.crw_walk_state_bytes(1, 8, 200, 2) > lib.crw_walk_state_bytes(1, 8, 200, 1) > 0
+
+
+def test_build_hook_with_and_without_a_prebuilt_library():
+    """`__graft_entry__.build()` is the driver's "does it build" check: it must succeed on a tree that already holds the
+    library and on one that does not (fresh clone: *.so is git-ignored), and the ABI number it checks is the header's."""
+    import shutil
+    import __graft_entry__
+    import crw_hip
+    header = open(os.path.join(ROOT, "include", "crw_hip.h")).read()
+    assert int(re.search(r"^#define\s+CRW_ABI_VERSION\s+(\d+)", header, re.M).group(1)) == crw_hip.ABI_VERSION
+    __graft_entry__.build()                       # library present (or built now)
+    assert os.path.exists(crw_hip.LIB_PATH)
+    aside = crw_hip.LIB_PATH + ".aside"
+    shutil.move(crw_hip.LIB_PATH, aside)
+    try:
+        __graft_entry__.build()                   # library absent: make links / compiles it again
+        assert os.path.exists(crw_hip.LIB_PATH)
+        assert ctypes.CDLL(crw_hip.LIB_PATH).crw_abi_version() == crw_hip.ABI_VERSION
+    finally:
+        if not os.path.exists(crw_hip.LIB_PATH):
+            shutil.move(aside, crw_hip.LIB_PATH)
+        elif os.path.exists(aside):
+            os.remove(aside)
 
 
 def test_cpu_tensors_are_refused():
