@@ -223,6 +223,83 @@ int crw_enc_front_bwd_map(int split, const float *x, int P, int cin, int H, int 
                           const uint16_t *w2b_lo, const float *dy, float *dw1, float *db1, float *dw2, float *db2,
                           void *ws, size_t ws_bytes, crw_stream_t stream);
 
+/* Resnet encoder (the reference's default model: src/encoder.py:63-89 stem, :109-155 BasicBlock, :157-272 body), forward AND
+ * backward on hand-written kernels ----------------------------------------------------------------------------------------
+ * Conventions of this group.  Ppad = crw_rn_padded_patches(P) (P rounded up to 128).  "planes" are channels-last bf16 pairs
+ * (hi, lo; x = hi + lo) of shape [Ppad][pixels][C] whose rows P..Ppad-1 are ZERO; raw convolution outputs are fp32
+ * [Ppad][pixels][C].  Every convolution runs as a matrix product ACROSS PATCHES (tile = 128 patches x 64/128 channels, one
+ * group per output pixel, reduction over the kernel taps that fall inside the map) on v_mfma_f32_16x16x32_bf16 with hi/lo
+ * operand pairs (3 products, fp32 accumulate).  Train-mode BatchNorm (nn.BatchNorm2d defaults) is split into: per-tile
+ * column statistics from the convolution's epilogue -> crw_rn_bn_stats -> crw_rn_bn_apply / crw_rn_bn_pool; backward
+ * crw_rn_bn_bwd / crw_rn_pool_bwd.  A BatchNorm's coefficients travel as coef[4][C] = scale, shift, mean, invstd. */
+int crw_rn_padded_patches(int P);
+/* conv weight [cout][cin][kh][kw] fp32 -> forward planes [cout][kh*kw][cin] and backward-data planes [cin][kh*kw][cout] */
+int crw_rn_pack_conv(const float *w, int cout, int cin, int kh, int kw, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi,
+                     uint16_t *bwd_lo, crw_stream_t stream);
+/* stem convolution model.conv1 [64][3][7][7] (src/encoder.py:185) for h x w patches: forward planes [64][256] and the Toeplitz
+ * planes [(h+2)][64][crw_rn_stem_toeplitz_ld(w)] of its backward-data product */
+int crw_rn_stem_toeplitz_ld(int w);
+int crw_rn_pack_stem(const float *w1, int h, int w, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *toep_hi, uint16_t *toep_lo,
+                     crw_stream_t stream);
+/* mode 0: forward of conv2d(kh x kw, stride, pad, no bias) -- a = input planes [Ppad][Hs*Ws][Cs], b = forward weight planes,
+ *         out fp32 [Ppad][Hd*Wd][N] (N = cout);  a linear layer is the 1x1 case on a 1x1 map (bias: optional [N]).
+ * mode 1: backward-data -- a = dZ planes on the OUTPUT map [Ppad][Hs*Ws][Cs] (Cs = cout), b = backward planes,
+ *         out = gradient on the input map [Ppad][Hd*Wd][N] (N = cin).
+ * mode 2: stem forward (7x7, stride 2) -- a = the zero-padded 4-channel map of crw_rn_stem_fwd [Ppad][Hs][Ws][4], b = forward
+ *         stem planes, out [Ppad][Hd*Wd][64].
+ * mode 3: stem backward-data -- a = dZ planes [Ppad][Hs*Ws][64], b = Toeplitz planes, out [Ppad][Hd][64]: row iy holds the
+ *         gradient of the (h+2) x (w+2) map at (iy, ix), channel c in column ix * 3 + c.
+ * part (may be NULL): crw_rn_conv_part_floats(P, Hd*Wd, N) floats of per-tile column sums / sums of squares for crw_rn_bn_stats. */
+size_t crw_rn_conv_part_floats(int P, int G, int N);
+int crw_rn_conv(int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int kh, int kw, int stride, int pad,
+                const uint16_t *a_hi, const uint16_t *a_lo, const uint16_t *b_hi, const uint16_t *b_lo, const float *bias, float *out,
+                float *part, crw_stream_t stream);
+/* weight gradient dw [cout][cin][kh][kw] (fp32, overwritten) from the input planes x [Ppad][Hin*Win][Cin] and the dZ planes
+ * [Ppad][Hout*Wout][Cout]; mode 0 = convolution / linear layer, mode 2 = stem (x = the 4-channel map, Hin x Win = its size,
+ * Cin = 4; dw = [64][3][7][7]).  Reduction over patches in slices, partial slabs in ws added in a fixed order. */
+size_t crw_rn_wgrad_ws_bytes(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad);
+int crw_rn_wgrad(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad,
+                 const uint16_t *x_hi, const uint16_t *x_lo, const uint16_t *d_hi, const uint16_t *d_lo, float *dw, void *ws,
+                 size_t ws_bytes, crw_stream_t stream);
+/* batch statistics of a convolution output with G pixels per patch from its `part` -> coef[4][C]; run_mean / run_var (may be
+ * NULL together) are updated like nn.BatchNorm2d in train mode (momentum on the batch mean and the unbiased batch variance) */
+size_t crw_rn_bn_stats_ws_bytes(int C);
+int crw_rn_bn_stats(const float *part, int P, int G, int C, const float *gamma, const float *beta, float *run_mean, float *run_var,
+                    float momentum, float eps, float *coef, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* y planes = relu?( Z * scale + shift [+ Zd * scale_d + shift_d] [+ residual planes] )   (src/encoder.py:138-153) */
+int crw_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
+                    const uint16_t *res_lo, int P, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream);
+/* y planes [Ppad][Ho*Wo][C] = maxpool3x3/2/1( relu( Z * scale + shift ) ), Z on an H x W map   (src/encoder.py:257-260) */
+int crw_rn_bn_pool(const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream);
+/* backward of y = relu(bn(Z) [+ bn_d(Zd)] [+ identity]): g = (g1 [+ g2]) where mask_hi (the hi plane of y) is non-zero;
+ * dz planes = gradient of Z, dzd planes = gradient of Zd, g_out (may be NULL) = g in fp32 (the identity shortcut's share),
+ * dgamma / dbeta [C] (and the shortcut BatchNorm's). */
+size_t crw_rn_bn_bwd_ws_bytes(int P, int npix, int C);
+int crw_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
+                  const float *coef_d, int P, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi, uint16_t *dzd_lo,
+                  float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws, size_t ws_bytes,
+                  crw_stream_t stream);
+/* backward of crw_rn_bn_pool: d1 (+ d2) = gradient of the pooled map [Ppad][25][C] fp32 -> dz planes [Ppad][81][C] (9 x 9 maps:
+ * 16 x 16 patches), dgamma / dbeta of that BatchNorm */
+size_t crw_rn_pool_bwd_ws_bytes(int P, int C);
+int crw_rn_pool_bwd(const float *d1, const float *d2, const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *dz_hi,
+                    uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* stem: relu0(bn0(fc0(x))) with fc0 = Conv2d(cin, 3, 1, padding 1) (src/encoder.py:66-74,87): x [P][cin][h][w] -> the map planes
+ * [Ppad][Hm][Wm][4] that feed the stem convolution (the (h+2) x (w+2) map at offset (3,3), zero elsewhere, channel 3 = 0);
+ * bn0's batch statistics follow from the moments of x.  stem [32] floats = the record crw_rn_stem_bwd needs. */
+size_t crw_rn_stem_ws_bytes(void);
+int crw_rn_stem_fwd(const float *x, int P, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0, const float *gamma,
+                    const float *beta, float *run_mean, float *run_var, float momentum, float eps, uint16_t *map_hi, uint16_t *map_lo,
+                    float *stem, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* dX0 = out of crw_rn_conv mode 3 -> dw0 [3][cin], db0 [3], dgamma0 [3], dbeta0 [3] */
+int crw_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
+                    float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* fp32 [P][C] -> planes [Ppad][C] */
+int crw_rn_split(const float *x, int P, int C, uint16_t *hi, uint16_t *lo, crw_stream_t stream);
+/* out [C] = column sums of x [rows][C] (bias gradient of the head), fixed order */
+size_t crw_rn_colsum_ws_bytes(int C);
+int crw_rn_colsum(const float *x, int rows, int C, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
+
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous
  * call, e.g. when timing the GEMM alone).  split = 1: plain bf16 operands; split = 3: hi/lo operand

@@ -72,6 +72,29 @@ SIGNATURES = {
                                    _c_sz, _p]),
     "crw_enc_front_bwd_map": (_c_int, [_c_int, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _c_sz, _p]),
+    # Resnet encoder kernels
+    "crw_rn_padded_patches": (_c_int, [_c_int]),
+    "crw_rn_pack_conv": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "crw_rn_stem_toeplitz_ld": (_c_int, [_c_int]),
+    "crw_rn_pack_stem": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "crw_rn_conv_part_floats": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_rn_conv": (_c_int, [_c_int] * 12 + [_p] * 8),
+    "crw_rn_wgrad_ws_bytes": (_c_sz, [_c_int] * 12),
+    "crw_rn_wgrad": (_c_int, [_c_int] * 12 + [_p] * 6 + [_c_sz, _p]),
+    "crw_rn_bn_stats_ws_bytes": (_c_sz, [_c_int]),
+    "crw_rn_bn_stats": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
+    "crw_rn_bn_apply": (_c_int, [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_rn_bn_pool": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_rn_bn_bwd_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "crw_rn_bn_bwd": (_c_int, [_p] * 7 + [_c_int] * 3 + [_p] * 10 + [_c_sz, _p]),
+    "crw_rn_pool_bwd_ws_bytes": (_c_sz, [_c_int, _c_int]),
+    "crw_rn_pool_bwd": (_c_int, [_p] * 4 + [_c_int] * 4 + [_p] * 5 + [_c_sz, _p]),
+    "crw_rn_stem_ws_bytes": (_c_sz, []),
+    "crw_rn_stem_fwd": (_c_int, [_p] + [_c_int] * 6 + [_p] * 6 + [_c_f, _c_f] + [_p] * 4 + [_c_sz, _p]),
+    "crw_rn_stem_bwd": (_c_int, [_p] * 5 + [_c_int] * 4 + [_p] * 5 + [_c_sz, _p]),
+    "crw_rn_split": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
+    "crw_rn_colsum_ws_bytes": (_c_sz, [_c_int]),
+    "crw_rn_colsum": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_sz, _p]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -479,3 +502,198 @@ def enc_front_bwd_map(split, x, w1, b1, w2f, b2, w2b, dy):
                                        _dev(dw2, "dw2"), _dev(db2, "db2"), ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()),
            "crw_enc_front_bwd_map")
     return dw1, db1, dw2, db2
+
+
+# ------------------------------------------------------------------------------ Resnet encoder kernels (crw_rn_*)
+RN_FWD, RN_BWD, RN_STEM_FWD, RN_STEM_BWD = 0, 1, 2, 3
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def rn_padded(P):
+    return lib().crw_rn_padded_patches(int(P))
+
+
+def rn_pack_conv(w):
+    """conv / linear weight [cout,cin,kh,kw] (or [cout,cin]) fp32 -> (fwd_hi, fwd_lo, bwd_hi, bwd_lo) bf16 planes."""
+    w = w.detach()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    mk = lambda: torch.empty(cout * cin * kh * kw, dtype=_BF, device=w.device)
+    fh, fl, bh, bl = mk(), mk(), mk(), mk()
+    _check(lib().crw_rn_pack_conv(_dev(w.contiguous(), "w"), cout, cin, kh, kw, _bf(fh, "fh"), _bf(fl, "fl"), _bf(bh, "bh"),
+                                  _bf(bl, "bl"), _stream()), "crw_rn_pack_conv")
+    return fh, fl, bh, bl
+
+
+def rn_pack_stem(w1, h, w):
+    """model.conv1 weight [64,3,7,7] -> (fwd_hi, fwd_lo [64*256], toeplitz_hi, toeplitz_lo [(h+2)*64*ld])."""
+    ld = lib().crw_rn_stem_toeplitz_ld(w)
+    fh = torch.empty(64 * 256, dtype=_BF, device=w1.device)
+    fl = torch.empty_like(fh)
+    th = torch.empty((h + 2) * 64 * ld, dtype=_BF, device=w1.device)
+    tl = torch.empty_like(th)
+    _check(lib().crw_rn_pack_stem(_dev(w1.detach().contiguous(), "w1"), h, w, _bf(fh, "fh"), _bf(fl, "fl"), _bf(th, "th"),
+                                  _bf(tl, "tl"), _stream()), "crw_rn_pack_stem")
+    return fh, fl, th, tl
+
+
+def rn_conv(mode, P, src, dst, N, k, stride, pad, a, b, bias=None, stats=False):
+    """a = (hi, lo) planes on the source map src = (Hs, Ws, Cs); b = (hi, lo) weight planes; dst = (Hd, Wd).
+    -> (out fp32 [Ppad, G*N], part | None)."""
+    Hs, Ws, Cs = src
+    Hd, Wd = dst
+    G = Hd if mode == RN_STEM_BWD else Hd * Wd
+    Ppad = rn_padded(P)
+    dev = a[0].device
+    out = torch.empty(Ppad, G * N, dtype=torch.float32, device=dev)
+    part = torch.empty(lib().crw_rn_conv_part_floats(P, G, N), dtype=torch.float32, device=dev) if stats else None
+    ev = _ev_begin()
+    _check(lib().crw_rn_conv(mode, P, Hs, Ws, Cs, Hd, Wd, N, k[0], k[1], stride, pad, _bf(a[0], "a_hi"), _bf(a[1], "a_lo"),
+                             _bf(b[0], "b_hi"), _bf(b[1], "b_lo"), _dev(bias, "bias") if bias is not None else None,
+                             _dev(out, "out"), _ptr(part), _stream()), "crw_rn_conv")
+    _ev_end(ev, ("rn_conv", mode, Hs * Ws, Cs, G, N, k[0], stride))
+    return out, part
+
+
+def rn_wgrad(mode, P, xin, xout, k, stride, pad, x, d):
+    """x = (hi, lo) input planes on xin = (Hin, Win, Cin), d = (hi, lo) dZ planes on xout = (Hout, Wout, Cout)
+    -> dw [cout, cin, kh, kw] ([64,3,7,7] for the stem)."""
+    Hin, Win, Cin = xin
+    Hout, Wout, Cout = xout
+    dev = x[0].device
+    geo = (mode, P, Hin, Win, Cin, Hout, Wout, Cout, k[0], k[1], stride, pad)
+    nbytes = lib().crw_rn_wgrad_ws_bytes(*geo)
+    if nbytes == 0:
+        raise RuntimeError(f"crw_rn_wgrad: unsupported geometry {geo}")
+    ws = _ws(nbytes, dev)
+    dw = torch.empty((64, 3, 7, 7) if mode == RN_STEM_FWD else (Cout, Cin, k[0], k[1]), dtype=torch.float32, device=dev)
+    ev = _ev_begin()
+    _check(lib().crw_rn_wgrad(*geo, _bf(x[0], "x_hi"), _bf(x[1], "x_lo"), _bf(d[0], "d_hi"), _bf(d[1], "d_lo"), _dev(dw, "dw"),
+                              _ptr(ws), nbytes, _stream()), "crw_rn_wgrad")
+    _ev_end(ev, ("rn_wgrad", mode, Hin * Win, Cin, Hout * Wout, Cout, k[0], stride))
+    return dw
+
+
+def rn_bn_stats(part, P, G, bn, momentum, update_running=True):
+    """per-tile statistics of a convolution output -> coef [4, C]; updates bn.running_mean / running_var in place."""
+    C = bn.weight.numel()
+    dev = part.device
+    coef = torch.empty(4, C, dtype=torch.float32, device=dev)
+    nbytes = lib().crw_rn_bn_stats_ws_bytes(C)
+    ws = _ws(nbytes, dev)
+    rm = bn.running_mean if (update_running and bn.running_mean is not None) else None
+    rv = bn.running_var if rm is not None else None
+    _check(lib().crw_rn_bn_stats(_dev(part, "part"), P, G, C, _dev(bn.weight.detach(), "gamma"), _dev(bn.bias.detach(), "beta"),
+                                 _ptr(rm), _ptr(rv), float(momentum), float(bn.eps), _dev(coef, "coef"), _ptr(ws), nbytes,
+                                 _stream()), "crw_rn_bn_stats")
+    return coef
+
+
+def rn_bn_apply(Z, coef, P, npix, C, Zd=None, coef_d=None, res=None, relu=True):
+    Ppad = rn_padded(P)
+    yh = torch.empty(Ppad, npix * C, dtype=_BF, device=Z.device)
+    yl = torch.empty_like(yh)
+    _check(lib().crw_rn_bn_apply(_dev(Z, "Z"), _dev(coef, "coef"), _ptr(Zd), _ptr(coef_d), _ptr(res[0]) if res else None,
+                                 _ptr(res[1]) if res else None, P, npix, C, int(relu), _bf(yh, "yh"), _bf(yl, "yl"), _stream()),
+           "crw_rn_bn_apply")
+    return yh, yl
+
+
+def rn_bn_pool(Z, coef, P, H, W, C):
+    Ppad = rn_padded(P)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    yh = torch.empty(Ppad, Ho * Wo * C, dtype=_BF, device=Z.device)
+    yl = torch.empty_like(yh)
+    _check(lib().crw_rn_bn_pool(_dev(Z, "Z"), _dev(coef, "coef"), P, H, W, C, _bf(yh, "yh"), _bf(yl, "yl"), _stream()),
+           "crw_rn_bn_pool")
+    return yh, yl
+
+
+def rn_bn_bwd(g1, g2, mask_hi, Z, coef, P, npix, C, Zd=None, coef_d=None, want_g=False):
+    """-> (dz (hi, lo), dzd (hi, lo) | None, g fp32 | None, dgamma, dbeta, dgamma_d | None, dbeta_d | None)"""
+    Ppad = rn_padded(P)
+    dev = Z.device
+    mk = lambda: torch.empty(Ppad, npix * C, dtype=_BF, device=dev)
+    dzh, dzl = mk(), mk()
+    dzdh, dzdl = (mk(), mk()) if Zd is not None else (None, None)
+    gout = torch.empty(Ppad, npix * C, dtype=torch.float32, device=dev) if want_g else None
+    vec = lambda: torch.empty(C, dtype=torch.float32, device=dev)
+    dg, db = vec(), vec()
+    dgd, dbd = (vec(), vec()) if Zd is not None else (None, None)
+    nbytes = lib().crw_rn_bn_bwd_ws_bytes(P, npix, C)
+    ws = _ws(nbytes, dev)
+    _check(lib().crw_rn_bn_bwd(_dev(g1, "g1"), _ptr(g2), _bf(mask_hi, "mask"), _dev(Z, "Z"), _dev(coef, "coef"), _ptr(Zd),
+                               _ptr(coef_d), P, npix, C, _bf(dzh, "dzh"), _bf(dzl, "dzl"), _ptr(dzdh), _ptr(dzdl), _ptr(gout),
+                               _ptr(dg), _ptr(db), _ptr(dgd), _ptr(dbd), _ptr(ws), nbytes, _stream()), "crw_rn_bn_bwd")
+    return (dzh, dzl), ((dzdh, dzdl) if Zd is not None else None), gout, dg, db, dgd, dbd
+
+
+def rn_pool_bwd(d1, d2, Z, coef, P, H, W, C):
+    Ppad = rn_padded(P)
+    dev = Z.device
+    dzh = torch.empty(Ppad, H * W * C, dtype=_BF, device=dev)
+    dzl = torch.empty_like(dzh)
+    dg = torch.empty(C, dtype=torch.float32, device=dev)
+    db = torch.empty_like(dg)
+    nbytes = lib().crw_rn_pool_bwd_ws_bytes(P, C)
+    ws = _ws(nbytes, dev)
+    _check(lib().crw_rn_pool_bwd(_dev(d1, "d1"), _ptr(d2), _dev(Z, "Z"), _dev(coef, "coef"), P, H, W, C, _bf(dzh, "dzh"),
+                                 _bf(dzl, "dzl"), _ptr(dg), _ptr(db), _ptr(ws), nbytes, _stream()), "crw_rn_pool_bwd")
+    return (dzh, dzl), dg, db
+
+
+def rn_stem_fwd(x, fc0, bn0, Hm, Wm, momentum, update_running=True):
+    """x [P,cin,h,w] -> (map (hi, lo) [Ppad, Hm*Wm*4], stem record [32])."""
+    P, cin, h, w = x.shape
+    Ppad = rn_padded(P)
+    dev = x.device
+    mh = torch.empty(Ppad, Hm * Wm * 4, dtype=_BF, device=dev)
+    ml = torch.empty_like(mh)
+    stem = torch.empty(32, dtype=torch.float32, device=dev)
+    nbytes = lib().crw_rn_stem_ws_bytes()
+    ws = _ws(nbytes, dev)
+    rm = bn0.running_mean if (update_running and bn0.running_mean is not None) else None
+    rv = bn0.running_var if rm is not None else None
+    _check(lib().crw_rn_stem_fwd(_dev(x, "x"), P, cin, h, w, Hm, Wm, _dev(fc0.weight.detach().reshape(3, cin).contiguous(), "w0"),
+                                 _dev(fc0.bias.detach(), "b0"), _dev(bn0.weight.detach(), "gamma"), _dev(bn0.bias.detach(), "beta"),
+                                 _ptr(rm), _ptr(rv), float(momentum), float(bn0.eps), _bf(mh, "mh"), _bf(ml, "ml"), _dev(stem, "stem"),
+                                 _ptr(ws), nbytes, _stream()), "crw_rn_stem_fwd")
+    return (mh, ml), stem
+
+
+def rn_stem_bwd(dX0, x, stem, w0, b0):
+    P, cin, h, w = x.shape
+    dev = x.device
+    dw0 = torch.empty(3, cin, 1, 1, dtype=torch.float32, device=dev)
+    db0, dg, db = (torch.empty(3, dtype=torch.float32, device=dev) for _ in range(3))
+    nbytes = lib().crw_rn_stem_ws_bytes()
+    ws = _ws(nbytes, dev)
+    _check(lib().crw_rn_stem_bwd(_dev(dX0, "dX0"), _dev(x, "x"), _dev(stem, "stem"), _dev(w0.reshape(3, cin).contiguous(), "w0"),
+                                 _dev(b0, "b0"), P, cin, h, w, _dev(dw0, "dw0"), _dev(db0, "db0"), _dev(dg, "dg"), _dev(db, "db"),
+                                 _ptr(ws), nbytes, _stream()), "crw_rn_stem_bwd")
+    return dw0, db0, dg, db
+
+
+def rn_split(x, P, C):
+    Ppad = rn_padded(P)
+    hi = torch.empty(Ppad, C, dtype=_BF, device=x.device)
+    lo = torch.empty_like(hi)
+    _check(lib().crw_rn_split(_dev(x, "x"), P, C, _bf(hi, "hi"), _bf(lo, "lo"), _stream()), "crw_rn_split")
+    return hi, lo
+
+
+def rn_colsum(x):
+    rows, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = lib().crw_rn_colsum_ws_bytes(C)
+    ws = _ws(nbytes, x.device)
+    _check(lib().crw_rn_colsum(_dev(x, "x"), rows, C, _dev(out, "out"), _ptr(ws), nbytes, _stream()), "crw_rn_colsum")
+    return out

@@ -1,0 +1,69 @@
+// Internal declarations shared by the Resnet encoder kernels (resnet_gemm.hip, resnet_bn.hip) and their C-ABI entry points
+// (resnet.hip).  Public interface: the crw_rn_* functions of include/crw_hip.h.
+#pragma once
+#include "crw_common.h"
+
+namespace crw {
+
+// which gather the "NN" kernel performs (see resnet_gemm.hip)
+constexpr int RN_MODE_FWD = 0;       // convolution forward: group = output pixel
+constexpr int RN_MODE_BWD = 1;       // backward-data: group = input pixel
+constexpr int RN_MODE_STEM_FWD = 2;  // 7x7/2 stem convolution on the zero-padded 4-channel map
+constexpr int RN_MODE_STEM_BWD = 3;  // its backward-data against the Toeplitz weight planes: group = map row
+
+struct RnConvArgs {
+  const uint16_t *a_hi, *a_lo;  // source planes [Mpad][lda]
+  const uint16_t *b_hi, *b_lo;  // weight planes [N][ldb] (k-contiguous)
+  float *out;                   // [Mpad][ldc]: group g writes columns [g*N, (g+1)*N)
+  float *part;                  // per-tile column sums / sums of squares [mtiles*2][G][N] float2, or null
+  const float *bias;            // [N] or null
+  long b_group_stride;          // RN_MODE_STEM_BWD: elements between the weight planes of consecutive groups
+  int lda, ldb, ldc, N, G, mtiles;
+  int mode;
+  int Hs, Ws, Cs;  // source map (A operand): height, width, channels
+  int Hd, Wd;      // destination map: G = Hd * Wd (RN_MODE_STEM_BWD: G = Hd)
+  int KH, KW, S, PAD;
+};
+int launch_rn_conv(const RnConvArgs &a, hipStream_t s);
+
+struct RnWgradArgs {
+  const uint16_t *x_hi, *x_lo;  // input-activation planes [Ppad][lda]
+  const uint16_t *d_hi, *d_lo;  // dZ planes [Ppad][ldb]
+  float *slab;                  // [S][taps][Mtot][Ntot] partial sums
+  int lda, ldb, Mtot, Ntot, taps, ktiles_p /* Ppad / 64 */, S;
+  int mode;                     // RN_MODE_FWD (taps of a convolution) or RN_MODE_STEM_FWD
+  int Hin, Win, Cin, Hout, Wout, Cout, KH, KW, St, PAD;
+  int rshift, rstride;          // r -> (r >> rshift) * rstride + (r & ((1 << rshift) - 1)); no segmentation: rshift = 30
+};
+int rn_wgrad_slices(const RnWgradArgs &a);
+int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s);
+
+// resnet_bn.hip ------------------------------------------------------------------------------------------------------------
+int launch_rn_bn_stats(const float *part, int R, int C, double count, const float *gamma, const float *beta, float *run_mean,
+                       float *run_var, float momentum, float eps, float *coef, double *ws /* 64 * 2C doubles */, hipStream_t s);
+int launch_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
+                       const uint16_t *res_lo, int P, int Ppad, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, hipStream_t s);
+int launch_rn_bn_pool(const float *Z, const float *coef, int P, int Ppad, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo,
+                      hipStream_t s);
+size_t rn_bn_bwd_ws_bytes(int P, int npix, int C);
+int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
+                     const float *coef_d, int P, int Ppad, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi,
+                     uint16_t *dzd_lo, float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws,
+                     hipStream_t s);
+size_t rn_pool_bwd_ws_bytes(int P, int C);
+int launch_rn_pool_bwd(const float *d1, const float *d2, const float *Z, const float *coef, int P, int Ppad, int H, int W, int C,
+                       uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s);
+size_t rn_stem_ws_bytes();
+int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
+                       const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,
+                       uint16_t *m_hi, uint16_t *m_lo, float *stem, void *ws, hipStream_t s);
+int launch_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
+                       int ldx, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, hipStream_t s);
+int launch_rn_pack_conv(const float *w, int cout, int cin, int T, uint16_t *fh, uint16_t *fl, uint16_t *bh, uint16_t *bl, hipStream_t s);
+int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, uint16_t *fh, uint16_t *fl, uint16_t *th, uint16_t *tl,
+                        hipStream_t s);
+int launch_rn_split(const float *x, long rows, long rows_pad, int C, uint16_t *hi, uint16_t *lo, hipStream_t s);
+size_t rn_colsum_ws_bytes(int W);
+int launch_rn_colsum(const float *x, int R, int W, float *out, void *ws, hipStream_t s);
+
+}  // namespace crw

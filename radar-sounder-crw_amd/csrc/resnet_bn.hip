@@ -1,0 +1,819 @@
+// Element-wise kernels of the Resnet encoder: train-mode BatchNorm (statistics merge, apply, backward), the 3x3/2 max-pool,
+// the 1x1 stem (fc0 + bn0 + relu0, reference src/encoder.py:66-74,86-87), weight packing, fp32 <-> bf16 hi/lo planes.
+// All HBM-bound, 16-byte accesses, channels-last.  Reductions are two-level with fixed summation order (double precision in the
+// merges): results are bitwise reproducible.
+//
+// Layout conventions (see resnet_gemm.hip): raw convolution outputs Z are fp32 [Ppad][pixels][C]; activations / gradients
+// that feed a matrix-core kernel are bf16 planes (hi, lo) of the same shape; rows of the patches P <= p < Ppad are ZERO in
+// every plane (the GEMM epilogues then need no row predicate and the padded rows add nothing to any statistic).
+// A BatchNorm's coefficients travel as coef[4][C] = (scale = gamma * invstd, shift = beta - mean * scale, mean, invstd).
+#include "crw_common.h"
+#include "resnet.h"
+
+namespace crw {
+namespace {
+
+__device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+struct Oct {  // eight consecutive channels
+  float v[8];
+};
+__device__ inline Oct load8(const float *p) {
+  const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+  return Oct{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ inline void store8(float *p, const Oct &o) {
+  *reinterpret_cast<float4 *>(p) = float4{o.v[0], o.v[1], o.v[2], o.v[3]};
+  *reinterpret_cast<float4 *>(p + 4) = float4{o.v[4], o.v[5], o.v[6], o.v[7]};
+}
+__device__ inline Oct load8_planes(const uint16_t *hi, const uint16_t *lo) {
+  const uint4 h = *reinterpret_cast<const uint4 *>(hi), l = *reinterpret_cast<const uint4 *>(lo);
+  const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+  Oct o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o.v[2 * i] = bf2f((uint16_t)(hw[i] & 0xffff)) + bf2f((uint16_t)(lw[i] & 0xffff));
+    o.v[2 * i + 1] = bf2f((uint16_t)(hw[i] >> 16)) + bf2f((uint16_t)(lw[i] >> 16));
+  }
+  return o;
+}
+__device__ inline void store8_planes(uint16_t *hi, uint16_t *lo, const Oct &o) {
+  uint32_t hw[4], lw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint16_t h0 = f2bf(o.v[2 * i]), h1 = f2bf(o.v[2 * i + 1]);
+    const uint16_t l0 = f2bf(o.v[2 * i] - bf2f(h0)), l1 = f2bf(o.v[2 * i + 1] - bf2f(h1));
+    hw[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    lw[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+  }
+  *reinterpret_cast<uint4 *>(hi) = uint4{hw[0], hw[1], hw[2], hw[3]};
+  *reinterpret_cast<uint4 *>(lo) = uint4{lw[0], lw[1], lw[2], lw[3]};
+}
+// sign bits of a hi plane: the activation was written as relu(.), so "> 0" is "hi != 0" (hi = 0 only for |x| < 2^-133)
+__device__ inline void load_mask8(const uint16_t *hi, bool (&m)[8]) {
+  const uint4 h = *reinterpret_cast<const uint4 *>(hi);
+  const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m[2 * i] = (hw[i] & 0xffff) != 0;
+    m[2 * i + 1] = (hw[i] >> 16) != 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ two-level column sums
+// in [R][W] fp32 -> out [ceil(R / RB)][W] double: block row r2 adds rows [r2*RB, (r2+1)*RB) in order
+__global__ __launch_bounds__(256) void rn_rows_reduce_kernel(const float *__restrict__ in, int R, int W, int RB,
+                                                             double *__restrict__ out) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  const int r0 = blockIdx.y * RB, r1 = min(R, r0 + RB);
+  double acc = 0.0;
+  for (int r = r0; r < r1; ++r) acc += (double)in[(long)r * W + w];
+  out[(long)blockIdx.y * W + w] = acc;
+}
+
+// sum of the R2 rows of part2 [R2][W] at column w, by the 4 row lanes of a 64-column block (fixed order)
+__device__ inline double merge_rows(const double *__restrict__ part2, int R2, int W, int w, int rl, double *sh /*[4][64]*/) {
+  double acc = 0.0;
+  if (w < W)
+    for (int r = rl; r < R2; r += 4) acc += part2[(long)r * W + w];
+  sh[rl * 64 + (threadIdx.x & 63)] = acc;
+  __syncthreads();
+  const int c = threadIdx.x & 63;
+  const double tot = (sh[c] + sh[64 + c]) + (sh[128 + c] + sh[192 + c]);
+  __syncthreads();
+  return tot;
+}
+
+// BatchNorm batch statistics -> coef (scale, shift, mean, invstd) and the running statistics (nn.BatchNorm2d: momentum on
+// the batch mean and the UNBIASED batch variance).  part2 [R2][C][2] = (sum, sum of squares); block = 64 channels x 4 row lanes.
+__global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const double *__restrict__ part2, int R2, int C, double count,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                             float momentum, float eps, float *__restrict__ coef) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const double s1 = merge_rows(part2, R2, 2 * C, 2 * c, rl, sh);
+  const double s2 = merge_rows(part2, R2, 2 * C, 2 * c + 1, rl, sh);
+  if (rl != 0 || c >= C) return;
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double scale = (double)gamma[c] * invstd;
+  coef[c] = (float)scale;
+  coef[C + c] = (float)((double)beta[c] - mean * scale);
+  coef[2 * C + c] = (float)mean;
+  coef[3 * C + c] = (float)invstd;
+  if (run_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
+    run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm apply
+// y = relu?( z * scale + shift  [+ zd * scale_d + shift_d]  [+ residual planes] ) -> planes; rows of p >= P are written as 0
+__global__ __launch_bounds__(256) void rn_bn_apply_kernel(const float *__restrict__ Z, const float *__restrict__ coef,
+                                                          const float *__restrict__ Zd, const float *__restrict__ coef_d,
+                                                          const uint16_t *__restrict__ res_hi, const uint16_t *__restrict__ res_lo,
+                                                          long real_oct, long total_oct, int C, int relu, uint16_t *__restrict__ y_hi,
+                                                          uint16_t *__restrict__ y_lo) {
+  const int c8 = C >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (long)gridDim.x * 256) {
+    Oct y;
+    if (i < real_oct) {
+      const int c = (int)(i % c8) * 8;
+      const Oct z = load8(Z + i * 8), s = load8(coef + c), t = load8(coef + C + c);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y.v[k] = z.v[k] * s.v[k] + t.v[k];
+      if (Zd) {
+        const Oct zd = load8(Zd + i * 8), sd = load8(coef_d + c), td = load8(coef_d + C + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y.v[k] += zd.v[k] * sd.v[k] + td.v[k];
+      }
+      if (res_hi) {
+        const Oct r = load8_planes(res_hi + i * 8, res_lo + i * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y.v[k] += r.v[k];
+      }
+      if (relu)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y.v[k] = fmaxf(y.v[k], 0.f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y.v[k] = 0.f;
+    }
+    store8_planes(y_hi + i * 8, y_lo + i * 8, y);
+  }
+}
+
+// relu(bn(z)) followed by the 3x3 / stride 2 / padding 1 max-pool (src/encoder.py:190-193,257-260): Z [Ppad][H*W][C] ->
+// planes [Ppad][Ho*Wo][C]
+__global__ __launch_bounds__(256) void rn_bn_pool_kernel(const float *__restrict__ Z, const float *__restrict__ coef, int P, long total_oct,
+                                                         int H, int W, int Ho, int Wo, int C, uint16_t *__restrict__ y_hi,
+                                                         uint16_t *__restrict__ y_lo) {
+  const int c8 = C >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c8) * 8;
+    const long op = i / c8;
+    const int o = (int)(op % (Ho * Wo));
+    const long p = op / (Ho * Wo);
+    Oct y;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y.v[k] = 0.f;  // relu output is >= 0 and every window holds at least one pixel
+    if (p < P) {
+      const Oct s = load8(coef + c), t = load8(coef + C + c);
+      const int oy = o / Wo, ox = o % Wo;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = 2 * ox + kx - 1;
+          if (ix < 0 || ix >= W) continue;
+          const Oct z = load8(Z + ((p * H + iy) * W + ix) * C + c);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) y.v[k] = fmaxf(y.v[k], z.v[k] * s.v[k] + t.v[k]);
+        }
+      }
+    }
+    store8_planes(y_hi + i * 8, y_lo + i * 8, y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm backward
+// g = (g1 [+ g2]) where the block's output activation is positive (mask plane); per channel: sum g, sum g * xhat, and for the
+// shortcut's BatchNorm (Zd) sum g * xhat_d.  Block = `rows_per_block` rows x all channels; block partials [nblk][NS][C].
+template <int NS>
+__global__ __launch_bounds__(256) void rn_bn_bwd_reduce_kernel(const float *__restrict__ g1, const float *__restrict__ g2,
+                                                               const uint16_t *__restrict__ mask_hi, const float *__restrict__ Z,
+                                                               const float *__restrict__ coef, const float *__restrict__ Zd,
+                                                               const float *__restrict__ coef_d, long rows, int rows_per_block, int C,
+                                                               float *__restrict__ part) {
+  extern __shared__ float red[];  // [lanes][NS][C]
+  const int c8 = C >> 3, lanes = 256 / c8;
+  const int co = threadIdx.x % c8, rl = threadIdx.x / c8, c = co * 8;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[NS][8];
+#pragma unroll
+  for (int n = 0; n < NS; ++n)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[n][k] = 0.f;
+  const Oct mean = load8(coef + 2 * C + c), istd = load8(coef + 3 * C + c);
+  Oct mean_d = mean, istd_d = istd;
+  if (NS == 3) {
+    mean_d = load8(coef_d + 2 * C + c);
+    istd_d = load8(coef_d + 3 * C + c);
+  }
+  if (rl < lanes)
+    for (long r = r0 + rl; r < r1; r += lanes) {
+      const long e = r * C + c;
+      Oct g = load8(g1 + e);
+      if (g2) {
+        const Oct h = load8(g2 + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g.v[k] += h.v[k];
+      }
+      bool m[8];
+      load_mask8(mask_hi + e, m);
+      const Oct z = load8(Z + e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float gv = m[k] ? g.v[k] : 0.f;
+        acc[0][k] += gv;
+        acc[1][k] += gv * ((z.v[k] - mean.v[k]) * istd.v[k]);
+      }
+      if (NS == 3) {
+        const Oct zd = load8(Zd + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[2][k] += (m[k] ? g.v[k] : 0.f) * ((zd.v[k] - mean_d.v[k]) * istd_d.v[k]);
+      }
+    }
+  if (rl < lanes)
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[(rl * NS + n) * C + c + k] = acc[n][k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < NS * C; j += 256) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * NS * C + j];
+    part[(long)blockIdx.x * NS * C + j] = s;
+  }
+}
+
+// part2 [R2][NS][C] -> bwd[NS+?]: dgamma, dbeta (and the shortcut BN's) + the per-channel constants of the apply pass:
+//   k[0][c] = sum g / n, k[1][c] = sum g xhat / n, k[2][c] = sum g xhat_d / n
+template <int NS>
+__global__ __launch_bounds__(256) void rn_bn_bwd_finalize_kernel(const double *__restrict__ part2, int R2, int C, double count,
+                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                 float *__restrict__ dgamma_d, float *__restrict__ dbeta_d,
+                                                                 float *__restrict__ kc) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) s[n] = merge_rows(part2, R2, NS * C, n * C + c, rl, sh);
+  if (rl != 0 || c >= C) return;
+  dbeta[c] = (float)s[0];
+  dgamma[c] = (float)s[1];
+  kc[c] = (float)(s[0] / count);
+  kc[C + c] = (float)(s[1] / count);
+  if (NS == 3) {
+    dbeta_d[c] = (float)s[0];
+    dgamma_d[c] = (float)s[2];
+    kc[2 * C + c] = (float)(s[2] / count);
+  }
+}
+
+// dZ = scale * (g - k0 - xhat * k1) -> planes (and the shortcut's dZd with its own scale / xhat_d / k2); g_out (optional):
+// the masked gradient itself in fp32 (the identity shortcut of layer1 carries it to the block input).  Rows p >= P -> 0.
+__global__ __launch_bounds__(256) void rn_bn_bwd_apply_kernel(const float *__restrict__ g1, const float *__restrict__ g2,
+                                                              const uint16_t *__restrict__ mask_hi, const float *__restrict__ Z,
+                                                              const float *__restrict__ coef, const float *__restrict__ Zd,
+                                                              const float *__restrict__ coef_d, const float *__restrict__ kc,
+                                                              long real_oct, long total_oct, int C, uint16_t *__restrict__ dz_hi,
+                                                              uint16_t *__restrict__ dz_lo, uint16_t *__restrict__ dzd_hi,
+                                                              uint16_t *__restrict__ dzd_lo, float *__restrict__ g_out) {
+  const int c8 = C >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (long)gridDim.x * 256) {
+    Oct dz, dzd, gm;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dz.v[k] = dzd.v[k] = gm.v[k] = 0.f;
+    if (i < real_oct) {
+      const int c = (int)(i % c8) * 8;
+      const long e = i * 8;
+      Oct g = load8(g1 + e);
+      if (g2) {
+        const Oct h = load8(g2 + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g.v[k] += h.v[k];
+      }
+      bool m[8];
+      load_mask8(mask_hi + e, m);
+      const Oct z = load8(Z + e), sc = load8(coef + c), mean = load8(coef + 2 * C + c), istd = load8(coef + 3 * C + c);
+      const Oct k0 = load8(kc + c), k1 = load8(kc + C + c);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        gm.v[k] = m[k] ? g.v[k] : 0.f;
+        dz.v[k] = sc.v[k] * (gm.v[k] - k0.v[k] - (z.v[k] - mean.v[k]) * istd.v[k] * k1.v[k]);
+      }
+      if (Zd) {
+        const Oct zd = load8(Zd + e), sd = load8(coef_d + c), md = load8(coef_d + 2 * C + c), id = load8(coef_d + 3 * C + c);
+        const Oct k2 = load8(kc + 2 * C + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dzd.v[k] = sd.v[k] * (gm.v[k] - k0.v[k] - (zd.v[k] - md.v[k]) * id.v[k] * k2.v[k]);
+      }
+    }
+    store8_planes(dz_hi + i * 8, dz_lo + i * 8, dz);
+    if (dzd_hi) store8_planes(dzd_hi + i * 8, dzd_lo + i * 8, dzd);
+    if (g_out) store8(g_out + i * 8, gm);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ max-pool + bn1 backward
+// Gradient of pooled = maxpool3x3/2(relu(bn(z))) on an H x W map (9 x 9 for 16x16 patches).  Thread = (patch, channel); the
+// map of that channel lives in registers.  The arg-max of a window is its FIRST maximum in row-major order (ATen's max_pool2d).
+template <int H, int W>
+struct PoolBwd {
+  static constexpr int HO = (H - 1) / 2 + 1, WO = (W - 1) / 2 + 1;
+  // z[i] = raw convolution output of pixel i, g[i] = gradient with respect to bn(z) at pixel i (relu gate applied)
+  __device__ static inline void run(const float *__restrict__ d1, const float *__restrict__ d2, const float *__restrict__ Z, long p, int c,
+                                    int C, float scale, float shift, float (&z)[H * W], float (&g)[H * W]) {
+#pragma unroll
+    for (int i = 0; i < H * W; ++i) {
+      z[i] = Z[(p * (H * W) + i) * C + c];
+      g[i] = 0.f;
+    }
+#pragma unroll
+    for (int oy = 0; oy < HO; ++oy)
+#pragma unroll
+      for (int ox = 0; ox < WO; ++ox) {
+        const long e = (p * (HO * WO) + oy * WO + ox) * C + c;
+        float d = d1[e];
+        if (d2) d += d2[e];
+        float best = -1.f;  // relu output >= 0
+        int am = -1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+              const float y = fmaxf(z[iy * W + ix] * scale + shift, 0.f);
+              if (y > best) {
+                best = y;
+                am = iy * W + ix;
+              }
+            }
+          }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) g[iy * W + ix] += (am == iy * W + ix) ? d : 0.f;
+          }
+      }
+#pragma unroll
+    for (int i = 0; i < H * W; ++i) g[i] = (z[i] * scale + shift) > 0.f ? g[i] : 0.f;
+  }
+};
+
+// block = 4 patches x 64 channels (blockIdx.y = channel block); partials [nblk][2][C]
+template <int H, int W>
+__global__ __launch_bounds__(256) void rn_pool_bwd_reduce_kernel(const float *__restrict__ d1, const float *__restrict__ d2,
+                                                                 const float *__restrict__ Z, const float *__restrict__ coef, int P, int C,
+                                                                 float *__restrict__ part) {
+  __shared__ float red[4][2][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long p = (long)blockIdx.x * 4 + pl;
+  float s0 = 0.f, s1 = 0.f;
+  if (p < P) {
+    float z[H * W], g[H * W];
+    PoolBwd<H, W>::run(d1, d2, Z, p, c, C, coef[c], coef[C + c], z, g);
+    const float mean = coef[2 * C + c], istd = coef[3 * C + c];
+#pragma unroll
+    for (int i = 0; i < H * W; ++i) {
+      s0 += g[i];
+      s1 += g[i] * ((z[i] - mean) * istd);
+    }
+  }
+  red[pl][0][cl] = s0;
+  red[pl][1][cl] = s1;
+  __syncthreads();
+  if (pl < 2) {
+    const float s = (red[0][pl][cl] + red[1][pl][cl]) + (red[2][pl][cl] + red[3][pl][cl]);
+    part[((long)blockIdx.x * 2 + pl) * C + c] = s;
+  }
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(256) void rn_pool_bwd_apply_kernel(const float *__restrict__ d1, const float *__restrict__ d2,
+                                                                const float *__restrict__ Z, const float *__restrict__ coef,
+                                                                const float *__restrict__ kc, int P, int Ppad, int C,
+                                                                uint16_t *__restrict__ dz_hi, uint16_t *__restrict__ dz_lo) {
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long p = (long)blockIdx.x * 4 + pl;
+  if (p >= Ppad) return;
+  if (p >= P) {
+#pragma unroll
+    for (int i = 0; i < H * W; ++i) {
+      dz_hi[(p * (H * W) + i) * C + c] = 0;
+      dz_lo[(p * (H * W) + i) * C + c] = 0;
+    }
+    return;
+  }
+  float z[H * W], g[H * W];
+  const float scale = coef[c];
+  PoolBwd<H, W>::run(d1, d2, Z, p, c, C, scale, coef[C + c], z, g);
+  const float mean = coef[2 * C + c], istd = coef[3 * C + c], k0 = kc[c], k1 = kc[C + c];
+#pragma unroll
+  for (int i = 0; i < H * W; ++i) {
+    const float dz = scale * (g[i] - k0 - (z[i] - mean) * istd * k1);
+    const uint16_t h = f2bf(dz);
+    dz_hi[(p * (H * W) + i) * C + c] = h;
+    dz_lo[(p * (H * W) + i) * C + c] = f2bf(dz - bf2f(h));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ stem: fc0 (1x1, padding 1) + bn0 + relu0
+// moments of the input patches: per block (sum x_i, sum x_i x_j) -> part [nblk][8] (cin <= 2: s0, s1, s00, s01, s11)
+__global__ __launch_bounds__(256) void rn_stem_moments_kernel(const float *__restrict__ x, int P, int cin, int hw, float *__restrict__ part) {
+  __shared__ float red[4][8];
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const long total = (long)P * hw;  // pixels
+  const long per = (total + gridDim.x - 1) / gridDim.x;
+  const long i0 = (long)blockIdx.x * per, i1 = min(total, i0 + per);
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const long p = i / hw, q = i % hw;
+    const float a = x[(p * cin) * hw + q];
+    s[0] += a;
+    s[2] += a * a;
+    if (cin == 2) {
+      const float b = x[(p * cin + 1) * hw + q];
+      s[1] += b;
+      s[3] += a * b;
+      s[4] += b * b;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) s[k] = wave_sum(s[k]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 8)
+    part[(long)blockIdx.x * 8 + threadIdx.x] =
+        threadIdx.x < 5 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+}
+
+// One thread: batch statistics of y_c = sum_i w[c][i] x~_i + b[c] over the zero-padded (h+2) x (w+2) map, from the input moments.
+// stem [32] (saved for the backward): [0..2] scale_c, [3..5] shift_c, [6..8] mean_c, [9..11] invstd_c, [12..17] a[c][i] = scale_c * w[c][i],
+// [18..20] d_c = scale_c * b_c + shift_c, [21..25] the moments (s0, s1, s00, s01, s11), [26] n
+__global__ void rn_stem_finalize_kernel(const double *__restrict__ part2, int R2, int cin, double n, const float *__restrict__ w0,
+                                        const float *__restrict__ b0, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                        float *__restrict__ run_mean, float *__restrict__ run_var, float momentum, float eps,
+                                        float *__restrict__ stem) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double m[5] = {0, 0, 0, 0, 0};
+  for (int r = 0; r < R2; ++r)
+    for (int k = 0; k < 5; ++k) m[k] += part2[(long)r * 8 + k];
+  const double mu[2] = {m[0] / n, m[1] / n};
+  const double cov[2][2] = {{m[2] / n - mu[0] * mu[0], m[3] / n - mu[0] * mu[1]}, {m[3] / n - mu[0] * mu[1], m[4] / n - mu[1] * mu[1]}};
+  for (int c = 0; c < 3; ++c) {
+    double mean = b0[c], var = 0.0;
+    for (int i = 0; i < cin; ++i) {
+      mean += (double)w0[c * cin + i] * mu[i];
+      for (int j = 0; j < cin; ++j) var += (double)w0[c * cin + i] * (double)w0[c * cin + j] * cov[i][j];
+    }
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps), scale = (double)gamma[c] * invstd, shift = (double)beta[c] - mean * scale;
+    stem[c] = (float)scale;
+    stem[3 + c] = (float)shift;
+    stem[6 + c] = (float)mean;
+    stem[9 + c] = (float)invstd;
+    for (int i = 0; i < 2; ++i) stem[12 + 2 * c + i] = i < cin ? (float)(scale * (double)w0[c * cin + i]) : 0.f;
+    stem[18 + c] = (float)(scale * (double)b0[c] + shift);
+    if (run_mean) {
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
+      run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
+    }
+  }
+  for (int k = 0; k < 5; ++k) stem[21 + k] = (float)m[k];
+  stem[26] = (float)n;
+}
+
+// x [P][cin][h][w] -> zero-padded 4-channel map planes [Ppad][Hm][Wm][4]: relu(bn0(fc0(x))) on the (h+2) x (w+2) map placed at
+// offset 3 (the padding of the 7x7 convolution), channel 3 = 0.  Thread = map pixel.
+__global__ __launch_bounds__(256) void rn_stem_apply_kernel(const float *__restrict__ x, const float *__restrict__ stem, int P, long total_px,
+                                                            int cin, int h, int w, int Hm, int Wm, uint16_t *__restrict__ m_hi,
+                                                            uint16_t *__restrict__ m_lo) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_px; i += (long)gridDim.x * 256) {
+    const int mx = (int)(i % Wm), my = (int)((i / Wm) % Hm);
+    const long p = i / ((long)Wm * Hm);
+    float v[3] = {0.f, 0.f, 0.f};
+    const int y0 = my - 3, x0 = mx - 3;  // position on the (h+2) x (w+2) map of fc0
+    if (p < P && y0 >= 0 && y0 < h + 2 && x0 >= 0 && x0 < w + 2) {
+      float xi[2] = {0.f, 0.f};
+      if (y0 >= 1 && y0 <= h && x0 >= 1 && x0 <= w)
+        for (int k = 0; k < cin; ++k) xi[k] = x[((p * cin + k) * h + (y0 - 1)) * w + (x0 - 1)];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = fmaxf(stem[12 + 2 * c] * xi[0] + stem[13 + 2 * c] * xi[1] + stem[18 + c], 0.f);
+    }
+    uint16_t hh[4], ll[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      hh[c] = f2bf(v[c]);
+      ll[c] = f2bf(v[c] - bf2f(hh[c]));
+    }
+    hh[3] = ll[3] = 0;
+    *reinterpret_cast<uint2 *>(m_hi + i * 4) = uint2{(uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16)};
+    *reinterpret_cast<uint2 *>(m_lo + i * 4) = uint2{(uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16)};
+  }
+}
+
+// Backward of the stem from dX0 [Ppad][H0][ldx] (columns ix * 3 + c: gradient of the conv1 input on the (h+2) x (w+2) map):
+// per block and channel c: S1 = sum g, S2 = sum g xhat_c, S3[i] = sum g x~_i with g = dX0 where relu0 passed.  part [nblk][16]
+// (c * 4 + {S1, S2, S3_0, S3_1}).
+__global__ __launch_bounds__(256) void rn_stem_bwd_reduce_kernel(const float *__restrict__ dX0, const float *__restrict__ x,
+                                                                 const float *__restrict__ stem, const float *__restrict__ w0,
+                                                                 const float *__restrict__ b0, int P, int cin, int h, int w, int ldx,
+                                                                 float *__restrict__ part) {
+  __shared__ float red[4][12];
+  const int H0 = h + 2, W0 = w + 2;
+  const long total = (long)P * H0 * W0;
+  const long per = (total + gridDim.x - 1) / gridDim.x;
+  const long i0 = (long)blockIdx.x * per, i1 = min(total, i0 + per);
+  float s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = 0.f;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const int x0 = (int)(i % W0), y0 = (int)((i / W0) % H0);
+    const long p = i / ((long)W0 * H0);
+    float xi[2] = {0.f, 0.f};
+    if (y0 >= 1 && y0 <= h && x0 >= 1 && x0 <= w)
+      for (int k = 0; k < cin; ++k) xi[k] = x[((p * cin + k) * h + (y0 - 1)) * w + (x0 - 1)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float y = stem[12 + 2 * c] * xi[0] + stem[13 + 2 * c] * xi[1] + stem[18 + c];
+      const float g = y > 0.f ? dX0[(p * H0 + y0) * ldx + x0 * 3 + c] : 0.f;
+      float pre = b0[c];
+      for (int k = 0; k < cin; ++k) pre += w0[c * cin + k] * xi[k];
+      const float xh = (pre - stem[6 + c]) * stem[9 + c];
+      s[c * 4] += g;
+      s[c * 4 + 1] += g * xh;
+      s[c * 4 + 2] += g * xi[0];
+      s[c * 4 + 3] += g * xi[1];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = wave_sum(s[k]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[threadIdx.x >> 6][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 16)
+    part[(long)blockIdx.x * 16 + threadIdx.x] =
+        threadIdx.x < 12 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+}
+
+// dgamma0 = S2, dbeta0 = S1; with dZ0 = scale (g - S1/n - xhat S2/n):  dw0[c][i] = sum dZ0 x~_i, db0[c] = sum dZ0 (= 0: sum xhat = 0)
+__global__ void rn_stem_bwd_finalize_kernel(const double *__restrict__ part2, int R2, int cin, const float *__restrict__ stem,
+                                            const float *__restrict__ w0, const float *__restrict__ b0, float *__restrict__ dw0,
+                                            float *__restrict__ db0, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double S[12];
+  for (int k = 0; k < 12; ++k) S[k] = 0.0;
+  for (int r = 0; r < R2; ++r)
+    for (int k = 0; k < 12; ++k) S[k] += part2[(long)r * 16 + k];
+  const double n = stem[26];
+  const double sx[2] = {stem[21], stem[22]};
+  const double sxx[2][2] = {{stem[23], stem[24]}, {stem[24], stem[25]}};
+  for (int c = 0; c < 3; ++c) {
+    const double S1 = S[c * 4], S2 = S[c * 4 + 1];
+    const double scale = stem[c], mean = stem[6 + c], invstd = stem[9 + c];
+    dgamma[c] = (float)S2;
+    dbeta[c] = (float)S1;
+    double sum_xh = 0.0;  // sum over the map of xhat_c (0 up to rounding)
+    for (int i = 0; i < cin; ++i) {
+      // sum xhat_c x~_i = invstd * (sum_j w[c][j] sum x~_j x~_i + (b_c - mean_c) sum x~_i)
+      double sxh = ((double)b0[c] - mean) * sx[i];
+      for (int j = 0; j < cin; ++j) sxh += (double)w0[c * cin + j] * sxx[j][i];
+      sxh *= invstd;
+      dw0[c * cin + i] = (float)(scale * (S[c * 4 + 2 + i] - S1 / n * sx[i] - S2 / n * sxh));
+      sum_xh += (double)w0[c * cin + i] * sx[i];
+    }
+    sum_xh = (sum_xh + ((double)b0[c] - mean) * n) * invstd;
+    db0[c] = (float)(-scale * S2 / n * sum_xh);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing, planes
+// w [cout][cin][T] fp32 -> forward planes [cout][T][cin], backward planes [cin][T][cout] (hi, lo)
+__global__ __launch_bounds__(256) void rn_pack_conv_kernel(const float *__restrict__ w, int cout, int cin, int T, uint16_t *__restrict__ fh,
+                                                           uint16_t *__restrict__ fl, uint16_t *__restrict__ bh, uint16_t *__restrict__ bl) {
+  const long total = (long)cout * cin * T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    // i indexes the forward plane [co][t][ci] (coalesced stores); the source read is strided
+    const int ci = (int)(i % cin), t = (int)((i / cin) % T), co = (int)(i / ((long)cin * T));
+    const float v = w[((long)co * cin + ci) * T + t];
+    const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+    fh[i] = h;
+    fl[i] = l;
+    const long j = ((long)ci * T + t) * cout + co;
+    bh[j] = h;
+    bl[j] = l;
+  }
+}
+
+// stem 7x7/2 weights w1 [64][3][7][7]:
+//   forward planes [64][256]: k = ky * 32 + kx * 4 + c (zero for ky = 7, kx = 7, c = 3)
+//   Toeplitz planes [H0][64][ldt] for the backward-data GEMM: row iy, column n = ix * 3 + c (zero for n >= 3 * W0),
+//     k = (oy - oy0(iy)) * (W1 * 64) + ox * 64 + co holds w1[co][c][iy + 3 - 2 oy][ix + 3 - 2 ox] (zero outside the kernel)
+__global__ __launch_bounds__(256) void rn_pack_stem_kernel(const float *__restrict__ w1, int H0, int W0, int H1, int W1, int ldt,
+                                                           uint16_t *__restrict__ fh, uint16_t *__restrict__ fl, uint16_t *__restrict__ th,
+                                                           uint16_t *__restrict__ tl) {
+  const long nf = 64 * 256, nt = (long)H0 * 64 * ldt;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nf + nt; i += (long)gridDim.x * 256) {
+    float v = 0.f;
+    if (i < nf) {
+      const int k = (int)(i & 255), co = (int)(i >> 8);
+      const int ky = k >> 5, kx = (k >> 2) & 7, c = k & 3;
+      if (ky < 7 && kx < 7 && c < 3) v = w1[((co * 3 + c) * 7 + ky) * 7 + kx];
+      const uint16_t h = f2bf(v);
+      fh[i] = h;
+      fl[i] = f2bf(v - bf2f(h));
+    } else {
+      const long j = i - nf;
+      const int k = (int)(j % ldt), n = (int)((j / ldt) % 64), iy = (int)(j / ((long)ldt * 64));
+      int oy0 = (iy + 3 - 7 + 2) / 2;
+      if (iy + 3 - 7 + 1 <= 0) oy0 = 0;
+      const int co = k & 63, ox = (k >> 6) % W1, oy = oy0 + (k >> 6) / W1;
+      const int ix = n / 3, c = n % 3;
+      const int ky = iy + 3 - 2 * oy, kx = ix + 3 - 2 * ox;
+      if (n < 3 * W0 && oy < H1 && ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w1[((co * 3 + c) * 7 + ky) * 7 + kx];
+      const uint16_t h = f2bf(v);
+      th[j] = h;
+      tl[j] = f2bf(v - bf2f(h));
+    }
+  }
+}
+
+// fp32 [rows][C] -> planes [rows_pad][C], zero rows beyond `rows`
+__global__ __launch_bounds__(256) void rn_split_kernel(const float *__restrict__ x, long real_oct, long total_oct, uint16_t *__restrict__ hi,
+                                                       uint16_t *__restrict__ lo) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (long)gridDim.x * 256) {
+    Oct v;
+    if (i < real_oct) v = load8(x + i * 8);
+    else
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] = 0.f;
+    store8_planes(hi + i * 8, lo + i * 8, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void rn_colsum_finalize_kernel(const double *__restrict__ part2, int R2, int W, float *__restrict__ out) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  double acc = 0.0;
+  for (int r = 0; r < R2; ++r) acc += part2[(long)r * W + w];
+  out[w] = (float)acc;
+}
+
+inline unsigned grid_for(long n, int per_block = 256, long cap = 8192) {
+  long b = (n + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+// in [R][W] fp32 -> ws (doubles) [R2][W]; returns R2
+int rn_rows_reduce(const float *in, int R, int W, double *ws, hipStream_t s) {
+  const int RB = (R + 63) / 64 > 0 ? (R + 63) / 64 : 1;
+  const int R2 = (R + RB - 1) / RB;
+  hipLaunchKernelGGL(rn_rows_reduce_kernel, dim3((W + 255) / 256, R2), dim3(256), 0, s, in, R, W, RB, ws);
+  return R2;
+}
+
+int launch_rn_bn_stats(const float *part, int R, int C, double count, const float *gamma, const float *beta, float *run_mean,
+                       float *run_var, float momentum, float eps, float *coef, double *ws, hipStream_t s) {
+  const int R2 = rn_rows_reduce(part, R, 2 * C, ws, s);
+  hipLaunchKernelGGL(rn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, R2, C, count, gamma, beta, run_mean, run_var,
+                     momentum, eps, coef);
+  return check_launch();
+}
+
+int launch_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
+                       const uint16_t *res_lo, int P, int Ppad, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, hipStream_t s) {
+  const long real = (long)P * npix * C / 8, total = (long)Ppad * npix * C / 8;
+  hipLaunchKernelGGL(rn_bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, coef, Zd, coef_d, res_hi, res_lo, real, total, C, relu,
+                     y_hi, y_lo);
+  return check_launch();
+}
+
+int launch_rn_bn_pool(const float *Z, const float *coef, int P, int Ppad, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo,
+                      hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)Ppad * Ho * Wo * C / 8;
+  hipLaunchKernelGGL(rn_bn_pool_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, coef, P, total, H, W, Ho, Wo, C, y_hi, y_lo);
+  return check_launch();
+}
+
+size_t rn_bn_bwd_ws_bytes(int P, int npix, int C) {
+  const long rows = (long)P * npix;
+  const long nblk = (rows + 255) / 256 + 1;
+  return align_up((size_t)nblk * 3 * C * 4, 256) + (size_t)64 * 3 * C * 8 + (size_t)3 * C * 4 + 256;
+}
+
+int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
+                     const float *coef_d, int P, int Ppad, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi,
+                     uint16_t *dzd_lo, float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws,
+                     hipStream_t s) {
+  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CRW_EINVAL;
+  const long rows = (long)P * npix;
+  int rpb = (int)((rows + 2047) / 2048);  // ~2048 blocks, at least 256 rows each (the workspace holds rows / 256 + 1 partials)
+  if (rpb < 256) rpb = 256;
+  const int nblk = (int)((rows + rpb - 1) / rpb);
+  const int NS = Zd ? 3 : 2;
+  float *part = (float *)ws;
+  double *part2 = (double *)((char *)ws + align_up((size_t)((rows + 255) / 256 + 1) * 3 * C * 4, 256));
+  float *kc = (float *)(part2 + (size_t)64 * 3 * C);
+  const size_t lds = (size_t)256 * 8 * NS * 4;
+  if (C / 8 > 256) return CRW_EINVAL;
+  if (NS == 3)
+    hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<3>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
+  else
+    hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<2>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
+  const int R2 = rn_rows_reduce(part, nblk, NS * C, part2, s);
+  if (NS == 3)
+    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<3>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
+                       dgamma_d, dbeta_d, kc);
+  else
+    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<2>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
+                       dgamma_d, dbeta_d, kc);
+  const long real = rows * C / 8, total = (long)Ppad * npix * C / 8;
+  hipLaunchKernelGGL(rn_bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, kc, real, total,
+                     C, dz_hi, dz_lo, dzd_hi, dzd_lo, g_out);
+  return check_launch();
+}
+
+size_t rn_pool_bwd_ws_bytes(int P, int C) {
+  const long nblk = (P + 3) / 4;
+  return align_up((size_t)nblk * 2 * C * 4, 256) + (size_t)64 * 2 * C * 8 + (size_t)2 * C * 4 + 256;
+}
+
+int launch_rn_pool_bwd(const float *d1, const float *d2, const float *Z, const float *coef, int P, int Ppad, int H, int W, int C,
+                       uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
+  if (H != 9 || W != 9 || C % 64) return CRW_EINVAL;  // 16x16 patches
+  const int nblk = (P + 3) / 4;
+  float *part = (float *)ws;
+  double *part2 = (double *)((char *)ws + align_up((size_t)nblk * 2 * C * 4, 256));
+  float *kc = (float *)(part2 + (size_t)64 * 2 * C);
+  hipLaunchKernelGGL((rn_pool_bwd_reduce_kernel<9, 9>), dim3(nblk, C / 64), dim3(256), 0, s, d1, d2, Z, coef, P, C, part);
+  const int R2 = rn_rows_reduce(part, nblk, 2 * C, part2, s);
+  hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<2>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)P * H * W, dgamma, dbeta,
+                     (float *)nullptr, (float *)nullptr, kc);
+  hipLaunchKernelGGL((rn_pool_bwd_apply_kernel<9, 9>), dim3((Ppad + 3) / 4, C / 64), dim3(256), 0, s, d1, d2, Z, coef, kc, P, Ppad, C,
+                     dz_hi, dz_lo);
+  return check_launch();
+}
+
+constexpr int STEM_BLOCKS = 1024;
+size_t rn_stem_ws_bytes() { return (size_t)STEM_BLOCKS * 16 * 4 + (size_t)64 * 16 * 8 + 256; }
+
+int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
+                       const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,
+                       uint16_t *m_hi, uint16_t *m_lo, float *stem, void *ws, hipStream_t s) {
+  float *part = (float *)ws;
+  double *part2 = (double *)((char *)ws + (size_t)STEM_BLOCKS * 16 * 4);
+  hipLaunchKernelGGL(rn_stem_moments_kernel, dim3(STEM_BLOCKS), dim3(256), 0, s, x, P, cin, h * w, part);
+  const int R2 = rn_rows_reduce(part, STEM_BLOCKS, 8, part2, s);
+  hipLaunchKernelGGL(rn_stem_finalize_kernel, dim3(1), dim3(64), 0, s, part2, R2, cin, (double)P * (h + 2) * (w + 2), w0, b0, gamma, beta,
+                     run_mean, run_var, momentum, eps, stem);
+  const long total_px = (long)Ppad * Hm * Wm;
+  hipLaunchKernelGGL(rn_stem_apply_kernel, dim3(grid_for(total_px)), dim3(256), 0, s, x, stem, P, total_px, cin, h, w, Hm, Wm, m_hi, m_lo);
+  return check_launch();
+}
+
+int launch_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
+                       int ldx, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
+  float *part = (float *)ws;
+  double *part2 = (double *)((char *)ws + (size_t)STEM_BLOCKS * 16 * 4);
+  hipLaunchKernelGGL(rn_stem_bwd_reduce_kernel, dim3(STEM_BLOCKS), dim3(256), 0, s, dX0, x, stem, w0, b0, P, cin, h, w, ldx, part);
+  const int R2 = rn_rows_reduce(part, STEM_BLOCKS, 16, part2, s);
+  hipLaunchKernelGGL(rn_stem_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, part2, R2, cin, stem, w0, b0, dw0, db0, dgamma, dbeta);
+  return check_launch();
+}
+
+int launch_rn_pack_conv(const float *w, int cout, int cin, int T, uint16_t *fh, uint16_t *fl, uint16_t *bh, uint16_t *bl, hipStream_t s) {
+  hipLaunchKernelGGL(rn_pack_conv_kernel, dim3(grid_for((long)cout * cin * T)), dim3(256), 0, s, w, cout, cin, T, fh, fl, bh, bl);
+  return check_launch();
+}
+
+int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, uint16_t *fh, uint16_t *fl, uint16_t *th, uint16_t *tl,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(rn_pack_stem_kernel, dim3(grid_for(64 * 256 + (long)H0 * 64 * ldt)), dim3(256), 0, s, w1, H0, W0, H1, W1, ldt, fh, fl,
+                     th, tl);
+  return check_launch();
+}
+
+int launch_rn_split(const float *x, long rows, long rows_pad, int C, uint16_t *hi, uint16_t *lo, hipStream_t s) {
+  hipLaunchKernelGGL(rn_split_kernel, dim3(grid_for(rows_pad * C / 8)), dim3(256), 0, s, x, rows * C / 8, rows_pad * C / 8, hi, lo);
+  return check_launch();
+}
+
+size_t rn_colsum_ws_bytes(int W) { return (size_t)64 * W * 8 + 256; }
+int launch_rn_colsum(const float *x, int R, int W, float *out, void *ws, hipStream_t s) {
+  const int R2 = rn_rows_reduce(x, R, W, (double *)ws, s);
+  hipLaunchKernelGGL(rn_colsum_finalize_kernel, dim3((W + 255) / 256), dim3(256), 0, s, (const double *)ws, R2, W, out);
+  return check_launch();
+}
+
+}  // namespace crw

@@ -1,0 +1,515 @@
+// Matrix-core kernels of the Resnet encoder (reference: src/encoder.py:63-89 stem, :109-155 BasicBlock, :157-272 body).
+//
+// At 16x16 patches the Resnet's feature maps are tiny (18^2 -> 9^2 -> 5^2 -> 5^2 -> 3^2 -> 2^2 -> 1), so every
+// convolution is computed as a GEMM ACROSS PATCHES: the M dimension of a tile is 128 patches, one "group" of the launch
+// is one output pixel, and the reduction runs over the taps of that pixel that fall inside the map (a 3x3 convolution on
+// the 1x1 map of layer4 is its centre tap only; nothing is multiplied by padding zeros).  Activations are channels-last
+// bf16 planes [Ppad][pixels][C] (hi and lo: x = hi + lo to ~2^-17, products as Ah*Bh + Ah*Bl + Al*Bh on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-grade results), Ppad = patches rounded up to 128 with ZERO rows, so
+// that for a fixed output pixel the operand row of patch p is a few contiguous channel vectors of that patch's record:
+//
+//   rn_conv_kernel   C[p][g][n] = sum_seg sum_c A[p][seg_a(g,seg) + c] * B[n][seg_b(g,seg) + c]         ("NN", k-contiguous operands)
+//       forward        g = output pixel, seg = in-range taps, A = input planes, B = weights [cout][tap][cin]
+//       backward-data  g = input pixel,  seg = (output pixel, tap) pairs that reach it, A = dZ planes, B = weights [cin][tap][cout]
+//       stem forward   7x7/2 on the 3-channel map, stored zero-padded with 4 channels: seg = kernel row, 32 contiguous values
+//       stem backward  g = map row, ONE contiguous segment of dZ rows against a Toeplitz expansion of the 7x7 weights
+//       the epilogue also emits per-tile column sums and sums of squares: the BatchNorm batch statistics cost no extra pass
+//   rn_wgrad_kernel  dW[tap][r][c] = sum_{pairs(tap)} sum_p X[p][pa(pair) + r] * dZ[p][pb(pair) + c]      ("TN", reduction over patches)
+//       both operands are patch-major, so their fragments come from ds_read_b64_tr_b16 (hardware transpose);
+//       split over patch slices, partial slabs added in a fixed order by rn_wgrad_reduce_kernel (no float atomics).
+//
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of lane-linear images with the bank swizzle on the source
+// address, counted vmcnt + raw s_barrier -- the staging scheme of gemm_bf16.hip, here with gathered / strided operands.
+#include "crw_common.h"
+#include "resnet.h"
+
+namespace crw {
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char *lds_cp;
+
+__device__ inline void glds16(const uint16_t *g, char *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ inline uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(lds_cp)p; }
+// inline asm: with the builtin hipcc drains every in-flight LDS-DMA in front of the read (gemm_bf16.hip)
+__device__ inline s4v tr_read(uint32_t lds_addr) {
+  s4v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+
+// ---- k-contiguous images: [rows][BK], 2*BK-byte rows, fragments by ds_read_b128 ---------------------------------------
+template <int BK>
+__device__ inline int kc_sw(int row) { return BK == 64 ? (row & 7) : ((row & 8) ? 3 : 0); }
+template <int BK>
+__device__ inline int kc_off(int row, int chunk) { return row * (2 * BK) + 16 * (chunk ^ kc_sw<BK>(row)); }
+template <int BK>
+__device__ inline bf8 kc_frag(const char *img, int rb, int s, int lane) {
+  return *reinterpret_cast<const bf8 *>(img + kc_off<BK>(rb + (lane & 15), 4 * s + (lane >> 4)));
+}
+
+// ---- r-contiguous images: [BK k-rows][TB], 2*TB-byte rows, fragments by two ds_read_b64_tr_b16 ------------------------
+// the chunk swizzle keeps the 32-byte windows that the eight k-rows of a half-wave read on distinct banks
+template <int TB>
+__device__ inline int rc_sw(int row) {
+  return TB == 64 ? ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1) : (((row & 3) << 2) | ((row >> 2) & 3));
+}
+template <int TB>
+__device__ inline int rc_off(int row, int chunk) { return row * (TB * 2) + 16 * (chunk ^ rc_sw<TB>(row)); }
+template <int TB>
+__device__ inline bf8 rc_frag(const char *img, int rb, int s, int lane) {
+  const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+  const int row = 32 * s + 8 * g + q;
+  const int chunk = (rb >> 3) + (p >> 1);
+  const uint32_t base = lds_addr_of(img);
+  const s4v lo = tr_read(base + rc_off<TB>(row, chunk) + 8 * (p & 1));
+  const s4v hi = tr_read(base + rc_off<TB>(row + 4, chunk) + 8 * (p & 1));
+  const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8, v);
+}
+
+__device__ inline f32x4 mfma(bf8 a, bf8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// bijective block -> work remap: blocks b, b+8, b+16, ... run on one XCD (speed only); every XCD gets a contiguous range of
+// the linear work index, so the blocks that share a patch tile (all groups / column tiles of it) meet in one 4 MiB L2
+__device__ inline int xcd_linear(int bid, int total) {
+  const int q = total >> 3, r = total & 7, x = bid & 7;
+  return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
+// =============================================================================================== NN: conv forward / backward-data
+constexpr int RN_MAXSEG = 64;
+
+template <int TN, int BK, int NSTAGE>
+struct NNCfg {
+  static constexpr int TM = 128, WAVES = 4, FM = 4, FN = TN / 32;
+  static constexpr int IMG_A = TM * 2 * BK, IMG_B = TN * 2 * BK, STAGE = 2 * IMG_A + 2 * IMG_B;
+  static constexpr int PA = TM * BK / 512 / WAVES, PB = TN * BK / 512 / WAVES;  // 1 KiB pieces per wave and image
+  static constexpr int G = 2 * PA + 2 * PB;                                     // LDS-DMA instructions per wave and k-tile
+  static constexpr int TABLE = 2 * RN_MAXSEG * 4 + 16;
+  static constexpr size_t LDS = (size_t)NSTAGE * STAGE + TABLE;
+  static_assert(PA >= 1 && PB >= 1, "pieces per wave");
+};
+
+// the segments of group g: seg_a[] = element offset of the segment inside an A row, seg_b[] = inside a B row
+__device__ inline void rn_segments(const RnConvArgs &a, int g, int lane, int *seg_a, int *seg_b, int *hdr) {
+  int nseg = 0, seglen = a.Cs;
+  if (a.mode == RN_MODE_FWD || a.mode == RN_MODE_BWD) {
+    const int T = a.KH * a.KW;
+    const int dy = g / a.Wd, dx = g % a.Wd;
+    bool valid = false;
+    int oa = 0;
+    if (lane < T) {
+      const int ky = lane / a.KW, kx = lane % a.KW;
+      if (a.mode == RN_MODE_FWD) {  // destination = output pixel, source = input map
+        const int iy = dy * a.S + ky - a.PAD, ix = dx * a.S + kx - a.PAD;
+        valid = iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
+        oa = (iy * a.Ws + ix) * a.Cs;
+      } else {                      // destination = input pixel, source = dZ map (output pixels)
+        const int ty = dy + a.PAD - ky, tx = dx + a.PAD - kx;
+        valid = ty >= 0 && tx >= 0 && ty % a.S == 0 && tx % a.S == 0 && ty / a.S < a.Hs && tx / a.S < a.Ws;
+        oa = ((ty / a.S) * a.Ws + tx / a.S) * a.Cs;
+      }
+    }
+    const unsigned long long m = __ballot(valid);
+    nseg = __popcll(m);
+    if (valid) {
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      seg_a[pos] = oa;
+      seg_b[pos] = lane * a.Cs;
+    }
+  } else if (a.mode == RN_MODE_STEM_FWD) {  // rows of the 7x7 kernel (+ one all-zero row): 32 contiguous values each
+    const int dy = g / a.Wd, dx = g % a.Wd;
+    nseg = 8;
+    seglen = 32;
+    if (lane < 8) {
+      seg_a[lane] = ((dy * a.S + lane) * a.Ws + dx * a.S) * a.Cs;
+      seg_b[lane] = lane * 32;
+    }
+  } else {  // RN_MODE_STEM_BWD: destination = map row g, ONE segment = the dZ rows whose kernel reaches it
+    int o0 = (g + a.PAD - a.KH + a.S) / a.S;  // ceil((g + PAD - KH + 1) / S) for a non-negative numerator, clamped below
+    if (g + a.PAD - a.KH + 1 <= 0) o0 = 0;
+    int o1 = (g + a.PAD) / a.S;
+    if (o1 > a.Hs - 1) o1 = a.Hs - 1;
+    nseg = 1;
+    seglen = (o1 - o0 + 1) * a.Ws * a.Cs;
+    if (lane == 0) {
+      seg_a[0] = o0 * a.Ws * a.Cs;
+      seg_b[0] = 0;
+    }
+  }
+  if (lane == 0) {
+    hdr[0] = nseg;
+    hdr[1] = nseg * seglen;                                   // K
+    hdr[2] = nseg == 1 ? 30 : 31 - __builtin_clz(seglen);     // k >> shift = segment
+  }
+}
+
+template <int TN, int BK, int NSTAGE>
+__global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {
+  using C = NNCfg<TN, BK, NSTAGE>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int *seg_a = reinterpret_cast<int *>(lds + NSTAGE * C::STAGE);
+  int *seg_b = seg_a + RN_MAXSEG;
+  int *hdr = seg_b + RN_MAXSEG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = a.N / TN;
+  const int lin = xcd_linear(blockIdx.x, gridDim.x);
+  const int per_mt = ntiles * a.G;
+  const int mt = lin / per_mt, rest = lin % per_mt;
+  const int g = rest / ntiles, nt = rest % ntiles;
+  const int m0 = mt * C::TM, n0 = nt * TN;
+
+  if (wave == 0) rn_segments(a, g, lane, seg_a, seg_b, hdr);
+  __syncthreads();
+  const int K = hdr[1], shift = hdr[2];
+  const int nkt = K / BK;
+  const unsigned kmask = (1u << shift) - 1u;
+
+  const uint16_t *Bh = a.b_hi + (long)g * a.b_group_stride, *Bl = a.b_lo + (long)g * a.b_group_stride;
+  // per-lane constants of the staging: which 16-byte chunk of a k-tile this lane fetches (swizzled) and its first row
+  constexpr int LPR = BK / 8, RPP = 64 / LPR;  // lanes per row, rows per 1 KiB piece
+  const int lrow = lane / LPR;
+  const int gchunk = (lane % LPR) ^ kc_sw<BK>(lrow);
+  const long a_row0 = (long)(m0 + lrow) * a.lda, b_row0 = (long)(n0 + lrow) * a.ldb;
+
+  auto stage = [&](int t, int buf) {
+    char *base = lds + buf * C::STAGE;
+    const unsigned k = (unsigned)(t * BK + 8 * gchunk);
+    const int sg = (int)(k >> shift), within = (int)(k & kmask);
+    const int acol = seg_a[sg] + within, bcol = seg_b[sg] + within;
+#pragma unroll
+    for (int i = 0; i < C::PA; ++i) {
+      const int piece = C::WAVES * i + wave;
+      const long off = a_row0 + (long)(RPP * piece) * a.lda + acol;
+      glds16(a.a_hi + off, base + piece * 1024);
+      glds16(a.a_lo + off, base + C::IMG_A + piece * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) {
+      const int piece = C::WAVES * i + wave;
+      const long off = b_row0 + (long)(RPP * piece) * a.ldb + bcol;
+      glds16(Bh + off, base + 2 * C::IMG_A + piece * 1024);
+      glds16(Bl + off, base + 2 * C::IMG_A + C::IMG_B + piece * 1024);
+    }
+  };
+
+  f32x4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (TN / 2);
+
+  for (int t = 0; t < NSTAGE - 1 && t < nkt; ++t) stage(t, t);
+  for (int t = 0; t < nkt; ++t) {
+    if (NSTAGE >= 3 && t + 1 < nkt)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::G) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; the buffer of tile t-1 is free
+    if (t + NSTAGE - 1 < nkt) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+    const char *base = lds + (t % NSTAGE) * C::STAGE;
+#pragma unroll
+    for (int s = 0; s < BK / 32; ++s) {
+      bf8 b[C::FN], bl[C::FN], af[C::FM], al[C::FM];
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        b[j] = kc_frag<BK>(base + 2 * C::IMG_A, wn + 16 * j, s, lane);
+        bl[j] = kc_frag<BK>(base + 2 * C::IMG_A + C::IMG_B, wn + 16 * j, s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i) {
+        af[i] = kc_frag<BK>(base, wm + 16 * i, s, lane);
+        al[i] = kc_frag<BK>(base + C::IMG_A, wm + 16 * i, s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) {
+          acc[i][j] = mfma(al[i], b[j], acc[i][j]);
+          acc[i][j] = mfma(af[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma(af[i], b[j], acc[i][j]);
+        }
+    }
+  }
+
+  // epilogue: fp32 tile (+ bias) and the per-tile column statistics
+  const long crow0 = (long)(m0 + wm + (lane >> 4) * 4) * a.ldc + (long)g * a.N + n0 + wn + (lane & 15);
+#pragma unroll
+  for (int j = 0; j < C::FN; ++j) {
+    const int col = n0 + wn + 16 * j + (lane & 15);
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[i][j][r] + bias;
+        a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    if (a.part) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 16) {
+        float2 *p = reinterpret_cast<float2 *>(a.part) + ((long)(mt * 2 + (wave >> 1)) * a.G + g) * a.N + col;
+        *p = float2{s1, s2};
+      }
+    }
+  }
+}
+
+template <int TN, int BK, int NSTAGE>
+int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
+  using C = NNCfg<TN, BK, NSTAGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)rn_conv_kernel<TN, BK, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::LDS) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr_set = true;
+  }
+  const int total = a.mtiles * (a.N / TN) * a.G;
+  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE>), dim3(total), dim3(256), C::LDS, s, a);
+  return check_launch();
+}
+
+// =============================================================================================== TN: weight gradients
+constexpr int RN_MAXPAIR = 128;
+
+template <int TM, int TN>
+struct TNCfg {
+  static constexpr int BK = 64, WAVES = 4, FM = TM / 32, FN = TN / 32, NSTAGE = 2;
+  static constexpr int IMG_A = TM * 2 * BK, IMG_B = TN * 2 * BK, STAGE = 2 * IMG_A + 2 * IMG_B;
+  static constexpr int PA = TM * BK / 512 / WAVES, PB = TN * BK / 512 / WAVES;
+  static constexpr int TABLE = 2 * RN_MAXPAIR * 4 + 16;
+  static constexpr size_t LDS = (size_t)NSTAGE * STAGE + TABLE;
+};
+
+// pairs of `tap`: pa[] = element offset of the input pixel inside an X row, pb[] = of the output pixel inside a dZ row
+__device__ inline void rn_pairs(const RnWgradArgs &a, int tap, int tid, int *pa, int *pb, int *hdr) {
+  // one wave (64 lanes), two rounds: up to 128 output pixels
+  int count = 0;
+  const int npix = a.Hout * a.Wout;
+  for (int base = 0; base < npix; base += 64) {
+    const int o = base + tid;
+    bool valid = false;
+    int va = 0;
+    if (o < npix) {
+      const int oy = o / a.Wout, ox = o % a.Wout;
+      if (a.mode == RN_MODE_STEM_FWD) {  // every output pixel; the kernel rows are the r-segments of the A operand
+        valid = true;
+        va = ((oy * a.St) * a.Win + ox * a.St) * a.Cin;
+      } else {
+        const int ky = tap / a.KW, kx = tap % a.KW;
+        const int iy = oy * a.St + ky - a.PAD, ix = ox * a.St + kx - a.PAD;
+        valid = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        va = (iy * a.Win + ix) * a.Cin;
+      }
+    }
+    const unsigned long long m = __ballot(valid);
+    if (valid) {
+      const int pos = count + __popcll(m & ((1ull << tid) - 1ull));
+      pa[pos] = va;
+      pb[pos] = o * a.Cout;
+    }
+    count += __popcll(m);
+  }
+  if (tid == 0) hdr[0] = count;
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
+  using C = TNCfg<TM, TN>;
+  constexpr int BK = C::BK;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int *pa = reinterpret_cast<int *>(lds + C::NSTAGE * C::STAGE);
+  int *pb = pa + RN_MAXPAIR;
+  int *hdr = pb + RN_MAXPAIR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mtiles = a.Mtot / TM, ntiles = a.Ntot / TN;
+  const int lin = blockIdx.x;
+  const int tap = lin / (mtiles * ntiles), mt = (lin / ntiles) % mtiles, nt = lin % ntiles;
+  const int slice = blockIdx.y;
+
+  if (wave == 0) rn_pairs(a, tap, lane, pa, pb, hdr);
+  __syncthreads();
+  const int npairs = hdr[0];
+  const long kt_total = (long)npairs * a.ktiles_p;
+  const int kt0 = (int)(kt_total * slice / a.S), kt1 = (int)(kt_total * (slice + 1) / a.S);
+
+  // staging constants: r-contiguous images, LPR lanes per k-row
+  constexpr int LPRA = TM / 8, RPPA = 64 / LPRA, LPRB = TN / 8, RPPB = 64 / LPRB;
+  const int r0 = mt * TM, c0 = nt * TN;
+
+  auto stage = [&](int kt, int buf) {
+    char *base = lds + buf * C::STAGE;
+    const int pair = kt / a.ktiles_p;
+    const int p0 = (kt - pair * a.ktiles_p) * BK;
+    const int oa = pa[pair], ob = pb[pair];
+#pragma unroll
+    for (int i = 0; i < C::PA; ++i) {
+      const int piece = C::WAVES * i + wave;
+      const int row = RPPA * piece + lane / LPRA;
+      const int r = r0 + 8 * ((lane % LPRA) ^ rc_sw<TM>(row));
+      const int roff = (r >> a.rshift) * a.rstride + (r & ((1 << a.rshift) - 1));  // stem: one kernel row = 32 values of a map row
+      const long off = (long)(p0 + row) * a.lda + oa + roff;
+      glds16(a.x_hi + off, base + piece * 1024);
+      glds16(a.x_lo + off, base + C::IMG_A + piece * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) {
+      const int piece = C::WAVES * i + wave;
+      const int row = RPPB * piece + lane / LPRB;
+      const int c = c0 + 8 * ((lane % LPRB) ^ rc_sw<TN>(row));
+      const long off = (long)(p0 + row) * a.ldb + ob + c;
+      glds16(a.d_hi + off, base + 2 * C::IMG_A + piece * 1024);
+      glds16(a.d_lo + off, base + 2 * C::IMG_A + C::IMG_B + piece * 1024);
+    }
+  };
+
+  f32x4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
+
+  if (kt0 < kt1) stage(kt0, 0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int it = kt - kt0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < kt1) stage(kt + 1, (it + 1) & 1);
+    const char *base = lds + (it & 1) * C::STAGE;
+#pragma unroll
+    for (int s = 0; s < BK / 32; ++s) {
+      bf8 b[C::FN], bl[C::FN], af[C::FM], al[C::FM];
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        b[j] = rc_frag<TN>(base + 2 * C::IMG_A, wn + 16 * j, s, lane);
+        bl[j] = rc_frag<TN>(base + 2 * C::IMG_A + C::IMG_B, wn + 16 * j, s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i) {
+        af[i] = rc_frag<TM>(base, wm + 16 * i, s, lane);
+        al[i] = rc_frag<TM>(base + C::IMG_A, wm + 16 * i, s, lane);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // inline-asm reads are invisible to the compiler's bookkeeping
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) {
+          acc[i][j] = mfma(al[i], b[j], acc[i][j]);
+          acc[i][j] = mfma(af[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma(af[i], b[j], acc[i][j]);
+        }
+    }
+  }
+
+  float *slab = a.slab + ((long)slice * a.taps + tap) * a.Mtot * a.Ntot;
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + wm + 16 * i + (lane >> 4) * 4 + r, col = c0 + wn + 16 * j + (lane & 15);
+        slab[(long)row * a.Ntot + col] = acc[i][j][r];
+      }
+}
+
+// dw (torch layout) = sum over slices of the slabs, in slice order
+//   conv:  dw[co][ci][tap] = sum_s slab[s][tap][ci][co]                      (Mtot = cin, Ntot = cout)
+//   stem:  dw[co][c][ky][kx] = sum_s slab[s][0][ky * 32 + kx * 4 + c][co]    (Mtot = 256, Ntot = 64, cin = 3, 7x7)
+__global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(const float *__restrict__ slab, int S, int taps, int Mtot, int Ntot,
+                                                              int stem, float *__restrict__ dw) {
+  const long per = (long)taps * Mtot * Ntot;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += slab[s * per + idx];
+  const int co = (int)(idx % Ntot);
+  const int r = (int)((idx / Ntot) % Mtot);
+  const int tap = (int)(idx / ((long)Ntot * Mtot));
+  if (stem) {
+    const int ky = r >> 5, kx = (r >> 2) & 7, c = r & 3;
+    if (ky < 7 && kx < 7 && c < 3) dw[((co * 3 + c) * 7 + ky) * 7 + kx] = acc;
+  } else {
+    dw[((long)co * Mtot + r) * taps + tap] = acc;
+  }
+}
+
+template <int TM, int TN>
+int launch_wgrad_cfg(const RnWgradArgs &a, hipStream_t s) {
+  using C = TNCfg<TM, TN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)rn_wgrad_kernel<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) !=
+        hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN>), dim3(a.taps * (a.Mtot / TM) * (a.Ntot / TN), a.S), dim3(256), C::LDS, s, a);
+  return check_launch();
+}
+
+}  // namespace
+
+int rn_conv_bk() {
+  static int bk = -1;
+  if (bk < 0) {
+    const char *e = getenv("CRW_RN_BK");  // A/B knob: 64 = one workgroup per CU, 32 = smaller stages, two per CU
+    bk = (e && atoi(e) == 32) ? 32 : 64;
+  }
+  return bk;
+}
+
+int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
+  if (a.N % 64 || a.mtiles < 1 || a.G < 1 || a.KH * a.KW > RN_MAXSEG) return CRW_EINVAL;
+  const bool wide = a.N % 128 == 0;
+  if (rn_conv_bk() == 32) return wide ? launch_conv_cfg<128, 32, 3>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);
+  return wide ? launch_conv_cfg<128, 64, 2>(a, s) : launch_conv_cfg<64, 64, 2>(a, s);
+}
+
+int rn_wgrad_slices(const RnWgradArgs &a) {
+  const int tm = a.Mtot % 128 ? 64 : 128, tn = a.Ntot % 128 ? 64 : 128;
+  const int tiles = a.taps * (a.Mtot / tm) * (a.Ntot / tn);
+  int S = (1024 + tiles - 1) / tiles;
+  const long kt = (long)a.Hout * a.Wout * a.ktiles_p;  // k-tiles of a tap that sees every output pixel
+  if (S > kt / 4) S = (int)(kt / 4);                   // at least four k-tiles per slice
+  if (S < 1) S = 1;
+  if (S > 256) S = 256;
+  return S;
+}
+
+int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s) {
+  if (a.Mtot % 64 || a.Ntot % 64 || a.Hout * a.Wout > RN_MAXPAIR || a.S < 1) return CRW_EINVAL;
+  const bool m128 = a.Mtot % 128 == 0, n128 = a.Ntot % 128 == 0;
+  int st;
+  if (m128 && n128) st = launch_wgrad_cfg<128, 128>(a, s);
+  else if (m128) st = launch_wgrad_cfg<128, 64>(a, s);
+  else if (n128) st = launch_wgrad_cfg<64, 128>(a, s);
+  else st = launch_wgrad_cfg<64, 64>(a, s);
+  if (st != CRW_OK) return st;
+  const long per = (long)a.taps * a.Mtot * a.Ntot;
+  hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, a.slab, a.S, a.taps, a.Mtot,
+                     a.Ntot, a.mode == RN_MODE_STEM_FWD ? 1 : 0, dw);
+  return check_launch();
+}
+
+}  // namespace crw

@@ -10,8 +10,8 @@ HIP kernels (``CNN.hip_convs``: "bf16x3" = hi/lo bf16 operand pairs on the matri
 results, the default; "bf16" = plain bf16 operands; None = PyTorch-ROCm ops).  Only the linear
 head stays a PyTorch op.  At other patch sizes the 3x3 trunk runs on the tiled variants of the same kernels (10x10 output
 tiles over the feature map): inference (``torch.no_grad``) the whole trunk incl. the front end (``_hip_inference_trunk``);
-training likewise, forward and backward (``_HipMapEncoder``).  CPU tensors and ``Resnet`` use PyTorch ops (a CUDA batch that
-misses the HIP path warns once).
+training likewise, forward and backward (``_HipMapEncoder``).  ``Resnet`` (16x16 patches, train mode) runs forward and backward on
+its own hand-written kernels (``resnet_hip``).  CPU tensors use PyTorch ops (a CUDA batch that misses the HIP path warns once).
 """
 import warnings
 
@@ -270,7 +270,13 @@ class _ResNetBody(nn.Module):
 
 
 class Resnet(nn.Module):
-    """1x1 conv (padding 1) + BN + ReLU lifting 1-2 channels to 3, then the ResNet body."""
+    """1x1 conv (padding 1) + BN + ReLU lifting 1-2 channels to 3, then the ResNet body.
+
+    On an MI355X, for 16x16 fp32 patches in train mode (the only mode the reference runs: it never calls ``.eval()``, so its
+    BatchNorms always use batch statistics), forward AND backward run on the hand-written HIP kernels (``resnet_hip``: every
+    convolution as a matrix-core product across patches, BatchNorm statistics from the convolutions' epilogues); ``hip_convs =
+    None`` selects the PyTorch ops, which also serve CPU tensors (host tests).  A CUDA batch that misses the HIP path warns once."""
+    _warned_fallback = False
 
     def __init__(self, pos_embed=True, pretrained=None):  # `pretrained` is ignored by the reference too
         super().__init__()
@@ -279,6 +285,16 @@ class Resnet(nn.Module):
         self.relu0 = nn.ReLU(inplace=True)
         self.model = _ResNetBody(FEATURE_DIM)
         self.num_params = _report(self)
+        self.hip_convs = "bf16x3"  # "bf16x3" (hi/lo bf16 operand pairs, fp32-grade) | None (PyTorch ops)
 
     def forward(self, x):
+        if self.hip_convs and x.is_cuda:
+            import resnet_hip
+            if resnet_hip.supported(x, self):
+                return resnet_hip.HipResnetFn.apply(x, self, *self.parameters())
+            if not Resnet._warned_fallback:
+                Resnet._warned_fallback = True
+                warnings.warn(f"Resnet.forward: input {tuple(x.shape)} {x.dtype} (training: {self.training}) is not covered by the HIP "
+                              "kernels (float32 16x16 patches in train mode on an MI355X): this call runs on PyTorch-ROCm / MIOpen",
+                              RuntimeWarning, stacklevel=2)
         return self.model(self.relu0(self.bn0(self.fc0(x))))

@@ -1,0 +1,155 @@
+"""``Resnet`` (the reference's default encoder, src/encoder.py:63-89 / :109-155 / :157-272) forward AND backward on the
+hand-written HIP kernels of csrc/resnet_gemm.hip + csrc/resnet_bn.hip, through the C ABI (``crw_rn_*``).
+
+Schedule of one training step for 16x16 patches (P patches; every convolution is a matrix product across patches, every
+BatchNorm runs on batch statistics exactly like ``nn.BatchNorm2d`` in train mode and updates its running statistics):
+
+    stem     fc0 (1x1, padding 1) + bn0 + relu0 -> zero-padded 4-channel 24x24 map          crw_rn_stem_fwd
+    conv1    7x7/2 (K = 8 kernel rows x 32) -> Z1 [P,81,64] + statistics                     crw_rn_conv mode 2, crw_rn_bn_stats
+    pool     relu(bn1(Z1)) -> 3x3/2 max-pool -> A1 [P,25,64]                                 crw_rn_bn_pool
+    layer1-4 conv3x3 -> bn -> relu -> conv3x3 -> bn (+ 1x1/2 shortcut conv -> bn | identity) -> relu
+                                                                                             crw_rn_conv mode 0, crw_rn_bn_stats, crw_rn_bn_apply
+    head     global average pool of the 1x1 map (identity) + linear 512 -> 128               crw_rn_conv mode 0 (1x1) + bias
+
+and the mirror image backwards (crw_rn_bn_bwd, crw_rn_conv mode 1, crw_rn_wgrad, crw_rn_pool_bwd, crw_rn_conv mode 3,
+crw_rn_stem_bwd).  No PyTorch / MIOpen convolution or batch-norm call is made on this path.
+"""
+import torch
+
+import crw_hip as H
+
+
+def supported(x, net):
+    """the HIP path covers fp32 16x16 patches on the GPU in train mode (the reference never calls .eval())"""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(x.shape[-2:]) == (16, 16) and x.shape[1] in (1, 2)
+            and net.training and net.bn0.momentum is not None)
+
+
+def _out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class _Block:
+    """geometry + modules of one BasicBlock"""
+
+    def __init__(self, mod, hin, win):
+        self.mod = mod
+        self.cin, self.cout = mod.conv1.in_channels, mod.conv1.out_channels
+        self.stride = mod.conv1.stride[0]
+        self.hin, self.win = hin, win
+        self.hout, self.wout = _out(hin, 3, self.stride, 1), _out(win, 3, self.stride, 1)
+
+
+class HipResnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        x = x.contiguous()
+        P, cin, h, w = x.shape
+        body = net.model
+        mom = net.bn0.momentum
+        H0, W0 = h + 2, w + 2
+        H1, W1 = _out(H0, 7, 2, 3), _out(W0, 7, 2, 3)
+        H2, W2 = _out(H1, 3, 2, 1), _out(W1, 3, 2, 1)
+        Hm, Wm = max(H0 + 6, 2 * H1 + 6), max(W0 + 6, 2 * W1 + 6)
+        blocks, hh, ww = [], H2, W2
+        for i in range(1, 5):
+            b = _Block(getattr(body, f"layer{i}")[0], hh, ww)
+            blocks.append(b)
+            hh, ww = b.hout, b.wout
+        if (hh, ww) != (1, 1) or (H1, W1) != (9, 9):
+            raise RuntimeError(f"HIP Resnet path: unsupported patch size {h}x{w}")
+        sv = {"geo": (P, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm), "x": x, "blocks": blocks}
+
+        # ---- stem
+        wstem = H.rn_pack_stem(body.conv1.weight, h, w)
+        xmap, stem = H.rn_stem_fwd(x, net.fc0, net.bn0, Hm, Wm, mom)
+        Z1, part = H.rn_conv(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1), 64, (7, 7), 2, 3, xmap, wstem[:2], stats=True)
+        coef1 = H.rn_bn_stats(part, P, H1 * W1, body.bn1, mom)
+        A = H.rn_bn_pool(Z1, coef1, P, H1, W1, 64)
+        sv.update(wstem=wstem, xmap=xmap, stem=stem, Z1=Z1, coef1=coef1)
+
+        # ---- residual stages
+        recs = []
+        for b in blocks:
+            m = b.mod
+            r = {"Ain": A}
+            r["wa"] = H.rn_pack_conv(m.conv1.weight)
+            r["wb"] = H.rn_pack_conv(m.conv2.weight)
+            npix = b.hout * b.wout
+            Za, part = H.rn_conv(H.RN_FWD, P, (b.hin, b.win, b.cin), (b.hout, b.wout), b.cout, (3, 3), b.stride, 1, A, r["wa"][:2],
+                                 stats=True)
+            r["Za"], r["ca"] = Za, H.rn_bn_stats(part, P, npix, m.bn1, mom)
+            r["Aa"] = H.rn_bn_apply(Za, r["ca"], P, npix, b.cout)
+            Zb, part = H.rn_conv(H.RN_FWD, P, (b.hout, b.wout, b.cout), (b.hout, b.wout), b.cout, (3, 3), 1, 1, r["Aa"], r["wb"][:2],
+                                 stats=True)
+            r["Zb"], r["cb"] = Zb, H.rn_bn_stats(part, P, npix, m.bn2, mom)
+            if m.downsample is not None:
+                r["wd"] = H.rn_pack_conv(m.downsample[0].weight)
+                Zd, part = H.rn_conv(H.RN_FWD, P, (b.hin, b.win, b.cin), (b.hout, b.wout), b.cout, (1, 1), b.stride, 0, A, r["wd"][:2],
+                                     stats=True)
+                r["Zd"], r["cd"] = Zd, H.rn_bn_stats(part, P, npix, m.downsample[1], mom)
+                A = H.rn_bn_apply(Zb, r["cb"], P, npix, b.cout, Zd=Zd, coef_d=r["cd"])
+            else:
+                A = H.rn_bn_apply(Zb, r["cb"], P, npix, b.cout, res=r["Ain"])
+            r["Aout"] = A
+            recs.append(r)
+
+        # ---- head (the average pool of a 1x1 map is the identity)
+        wfc = H.rn_pack_conv(body.fc.weight)
+        out, _ = H.rn_conv(H.RN_FWD, P, (1, 1, 512), (1, 1), body.fc.out_features, (1, 1), 1, 0, A, wfc[:2], bias=body.fc.bias.detach())
+        sv.update(recs=recs, wfc=wfc, Alast=A)
+        bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        ctx.sv = sv
+        ctx.net = net
+        ctx.names = [k for k, _ in net.named_parameters()]
+        return out[:P]
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("the HIP Resnet path does not produce a gradient for its input patches (the reference never asks for one)")
+        sv, net = ctx.sv, ctx.net
+        body = net.model
+        P, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm = sv["geo"]
+        grads = {}
+        dout = dout.contiguous().float()
+        dO = H.rn_split(dout, P, dout.shape[1])
+        nout = dout.shape[1]
+        grads["model.fc.weight"] = H.rn_wgrad(H.RN_FWD, P, (1, 1, 512), (1, 1, nout), (1, 1), 1, 0, sv["Alast"], dO).reshape(nout, 512)
+        grads["model.fc.bias"] = H.rn_colsum(dout)
+        g1, _ = H.rn_conv(H.RN_BWD, P, (1, 1, nout), (1, 1), 512, (1, 1), 1, 0, dO, sv["wfc"][2:])
+        g2 = None
+        for i in (3, 2, 1, 0):
+            b, r = sv["blocks"][i], sv["recs"][i]
+            m = b.mod
+            pre = f"model.layer{i + 1}.0."
+            npix = b.hout * b.wout
+            has_d = m.downsample is not None
+            dzb, dzd, gres, dg, db, dgd, dbd = H.rn_bn_bwd(g1, g2, r["Aout"][0], r["Zb"], r["cb"], P, npix, b.cout,
+                                                          Zd=r.get("Zd"), coef_d=r.get("cd"), want_g=not has_d)
+            grads[pre + "bn2.weight"], grads[pre + "bn2.bias"] = dg, db
+            grads[pre + "conv2.weight"] = H.rn_wgrad(H.RN_FWD, P, (b.hout, b.wout, b.cout), (b.hout, b.wout, b.cout), (3, 3), 1, 1,
+                                                     r["Aa"], dzb)
+            gA, _ = H.rn_conv(H.RN_BWD, P, (b.hout, b.wout, b.cout), (b.hout, b.wout), b.cout, (3, 3), 1, 1, dzb, r["wb"][2:])
+            dza, _, _, dg, db, _, _ = H.rn_bn_bwd(gA, None, r["Aa"][0], r["Za"], r["ca"], P, npix, b.cout)
+            grads[pre + "bn1.weight"], grads[pre + "bn1.bias"] = dg, db
+            grads[pre + "conv1.weight"] = H.rn_wgrad(H.RN_FWD, P, (b.hin, b.win, b.cin), (b.hout, b.wout, b.cout), (3, 3), b.stride, 1,
+                                                     r["Ain"], dza)
+            g1, _ = H.rn_conv(H.RN_BWD, P, (b.hout, b.wout, b.cout), (b.hin, b.win), b.cin, (3, 3), b.stride, 1, dza, r["wa"][2:])
+            if has_d:
+                grads[pre + "downsample.1.weight"], grads[pre + "downsample.1.bias"] = dgd, dbd
+                grads[pre + "downsample.0.weight"] = H.rn_wgrad(H.RN_FWD, P, (b.hin, b.win, b.cin), (b.hout, b.wout, b.cout), (1, 1),
+                                                                b.stride, 0, r["Ain"], dzd)
+                g2, _ = H.rn_conv(H.RN_BWD, P, (b.hout, b.wout, b.cout), (b.hin, b.win), b.cin, (1, 1), b.stride, 0, dzd, r["wd"][2:])
+            else:
+                g2 = gres
+        # max-pool + bn1, stem convolution, stem
+        dz1, dg, db = H.rn_pool_bwd(g1, g2, sv["Z1"], sv["coef1"], P, H1, W1, 64)
+        grads["model.bn1.weight"], grads["model.bn1.bias"] = dg, db
+        grads["model.conv1.weight"] = H.rn_wgrad(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1, 64), (7, 7), 2, 3, sv["xmap"], dz1)
+        dX0, _ = H.rn_conv(H.RN_STEM_BWD, P, (H1, W1, 64), (H0, 1), 64, (7, 7), 2, 3, dz1, sv["wstem"][2:])
+        dw0, db0, dg, db = H.rn_stem_bwd(dX0, sv["x"], sv["stem"], net.fc0.weight.detach(), net.fc0.bias.detach())
+        grads["fc0.weight"], grads["fc0.bias"], grads["bn0.weight"], grads["bn0.bias"] = dw0, db0, dg, db
+        ctx.sv = None
+        return (None, None) + tuple(grads[k] for k in ctx.names)
