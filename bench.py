@@ -127,6 +127,64 @@ def chain_probe_bf16(n, batch, split, iters=10):
     return ms, 2.0 * n ** 3 * batch * (3 if split == 3 else 1)
 
 
+def _rn_pairs(Hin, Win, Hout, Wout, k, stride, pad):
+    """number of (output pixel, tap) pairs of a k x k convolution whose tap falls inside the Hin x Win input map"""
+    n = 0
+    for oy in range(Hout):
+        for ox in range(Wout):
+            for ky in range(k):
+                for kx in range(k):
+                    iy, ix = oy * stride + ky - pad, ox * stride + kx - pad
+                    n += 0 <= iy < Hin and 0 <= ix < Win
+    return n
+
+
+def resnet_event_kernels(ev, P, steps):
+    """roofline lines of the Resnet matrix-core kernels from the HIP events of the timed steps (crw_hip.rn_conv / rn_wgrad).
+    Algorithmic flops of a convolution pass = 2 * P * pairs * cin * cout with pairs = the (output pixel, tap) pairs whose tap lies
+    inside the input map (multiplications by padding zeros are not counted: a 3x3 convolution on layer4's 1x1 map is 1 tap)."""
+    import crw_hip
+    out = []
+    for key, pairs in ev.items():
+        kind, mode = key[0], key[1]
+        if kind == "rn_conv":
+            _, _, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad = key
+            if mode == crw_hip.RN_FWD:
+                alg, ex = 2.0 * P * _rn_pairs(Hs, Ws, Hd, Wd, k, stride, pad) * Cs * N, 1.0
+                name = f"rn_conv_kernel fwd {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
+            elif mode == crw_hip.RN_BWD:
+                alg, ex = 2.0 * P * _rn_pairs(Hd, Wd, Hs, Ws, k, stride, pad) * Cs * N, 1.0
+                name = f"rn_conv_kernel bwd-data {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
+            elif mode == crw_hip.RN_STEM_FWD:
+                alg, ex = 2.0 * P * Hd * Wd * 147 * 64, 256.0 / 147.0   # K = 8 kernel rows x 32 for the 7 x 7 x 3 = 147 taps
+                name = "rn_conv_kernel stem fwd 7x7/2 3 -> 64"
+            else:
+                alg = 2.0 * P * 81 * 147 * 64
+                # executed: 18 map rows x 64 columns x the dZ rows each one sees (Toeplitz planes: zeros are multiplied)
+                rows = sum(min(8, (iy + 3) // 2) - max(0, (iy - 2) // 2 if iy > 3 else 0) + 1 for iy in range(Hd))
+                ex = (2.0 * P * 64 * rows * 9 * 64) / alg
+                name = "rn_conv_kernel stem bwd-data (Toeplitz) 64 -> 3"
+        else:
+            _, _, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad = key
+            if mode == crw_hip.RN_FWD:
+                alg, ex = 2.0 * P * _rn_pairs(Hin, Win, Hout, Wout, k, stride, pad) * Cin * Cout, 1.0
+                name = f"rn_wgrad_kernel {Hin}x{Win}x{Cin} -> {Hout}x{Wout}x{Cout} k{k}/s{stride} (+ slab sum)"
+            else:
+                alg, ex = 2.0 * P * Hout * Wout * 147 * 64, 256.0 / 147.0
+                name = "rn_wgrad_kernel stem 7x7/2 (+ slab sum)"
+        kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
+        out.append({"kernel": name, "bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
+                    "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                    "mfma_executed_tflops": alg * 3 * ex / (kms * 1e-3) / 1e12,
+                    "mfma_executed_frac": alg * 3 * ex / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                    "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // steps, "timed_launches": len(pairs),
+                    "algorithmic_flops_per_launch": alg,
+                    "note": "achieved = algorithmic (fp32-equivalent, in-map taps only) flops / mean HIP-event time of this kernel's launches "
+                            "INSIDE the timed steps; every product is 3 bf16 MFMAs on hi/lo operand pairs"})
+    out.sort(key=lambda k_: -k_["launch_us"] * k_["launches_per_step"])
+    return out
+
+
 def cpu_baseline(budget_s):
     """The oracle (pure torch-CPU restatement, validated against the reference) timed on this
     box's host cores on a bounded sample of the same workload: ONE item [1,32,63,16,16] per step."""
@@ -389,6 +447,8 @@ def main():
     enc = crw_utils.create_model(args.model, False)
     if args.model == 0:
         enc.hip_convs = None if args.convs == "torch" else args.convs
+    elif args.convs == "torch":
+        enc.hip_convs = None  # Resnet on PyTorch-ROCm / MIOpen (the round-2 path), for comparison
     net = crw_model.CRW(enc, TAU, False).to(device)
     net.train(True)
     bucket = crw_dist.FlatGradBucket(net.parameters(), lazy=True)
@@ -435,15 +495,19 @@ def main():
             "unit": "radargram columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16x3": "f32 (conv2-5 multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; everything else fp32)",
-                      "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else "torch"],
+                      "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else ("bf16x3" if getattr(enc, "hip_convs", None) else "torch")],
             "data": "synthetic",
             "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
                                    f"[T={T},N={N},16x16] (patch 16x16, overlap {OVERLAP}), tau={TAU}, "
                                    f"{'CNN' if args.model == 0 else 'Resnet'} encoder, fwd+bwd+all-reduce+Adam",
                        "columns_per_step_per_gpu": cols_per_step, "parallelism": f"dp{world} (independent sequences)",
-                       "chain": "fp32 MFMA 16x16x4, prefix form", "encoder_convs": args.convs, "loss": final_loss},
+                       "chain": "fp32 MFMA 16x16x4, prefix form",
+                       "encoder_convs": args.convs if (args.model == 0 or args.convs == "torch") else "bf16x3 (resnet_hip)", "loss": final_loss},
         }
         kernels = []
+        if crw_hip.KERNEL_EVENTS and args.model == 1:
+            ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+            kernels = resnet_event_kernels(ev, B * T * N, args.steps)
         if crw_hip.KERNEL_EVENTS:
             # per-kernel durations measured live over the timed region (HIP events on the launch stream)
             ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None

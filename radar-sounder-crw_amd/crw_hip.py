@@ -559,7 +559,7 @@ def rn_conv(mode, P, src, dst, N, k, stride, pad, a, b, bias=None, stats=False):
     _check(lib().crw_rn_conv(mode, P, Hs, Ws, Cs, Hd, Wd, N, k[0], k[1], stride, pad, _bf(a[0], "a_hi"), _bf(a[1], "a_lo"),
                              _bf(b[0], "b_hi"), _bf(b[1], "b_lo"), _dev(bias, "bias") if bias is not None else None,
                              _dev(out, "out"), _ptr(part), _stream()), "crw_rn_conv")
-    _ev_end(ev, ("rn_conv", mode, Hs * Ws, Cs, G, N, k[0], stride))
+    _ev_end(ev, ("rn_conv", mode, Hs, Ws, Cs, Hd, Wd, N, k[0], stride, pad))
     return out, part
 
 
@@ -578,7 +578,7 @@ def rn_wgrad(mode, P, xin, xout, k, stride, pad, x, d):
     ev = _ev_begin()
     _check(lib().crw_rn_wgrad(*geo, _bf(x[0], "x_hi"), _bf(x[1], "x_lo"), _bf(d[0], "d_hi"), _bf(d[1], "d_lo"), _dev(dw, "dw"),
                               _ptr(ws), nbytes, _stream()), "crw_rn_wgrad")
-    _ev_end(ev, ("rn_wgrad", mode, Hin * Win, Cin, Hout * Wout, Cout, k[0], stride))
+    _ev_end(ev, ("rn_wgrad", mode, Hin, Win, Cin, Hout, Wout, Cout, k[0], stride, pad))
     return dw
 
 

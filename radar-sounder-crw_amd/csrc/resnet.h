@@ -29,11 +29,14 @@ int launch_rn_conv(const RnConvArgs &a, hipStream_t s);
 struct RnWgradArgs {
   const uint16_t *x_hi, *x_lo;  // input-activation planes [Ppad][lda]
   const uint16_t *d_hi, *d_lo;  // dZ planes [Ppad][ldb]
-  float *slab;                  // [S][taps][Mtot][Ntot] partial sums
+  float *slab;                  // [S][ntv][Mtot][Ntot] partial sums
   int lda, ldb, Mtot, Ntot, taps, ktiles_p /* Ppad / 64 */, S;
   int mode;                     // RN_MODE_FWD (taps of a convolution) or RN_MODE_STEM_FWD
   int Hin, Win, Cin, Hout, Wout, Cout, KH, KW, St, PAD;
   int rshift, rstride;          // r -> (r >> rshift) * rstride + (r & ((1 << rshift) - 1)); no segmentation: rshift = 30
+  int ntv;                      // taps that reach the input map for at least one output pixel (the others have a zero gradient) ...
+  unsigned char tapv[64];       // ... their indices; the slabs hold only these
+  signed char tapinv[64];       // tap -> position in tapv, or -1
 };
 int rn_wgrad_slices(const RnWgradArgs &a);
 int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s);

@@ -94,6 +94,21 @@ static int wgrad_args(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin
     a.rshift = 5;
     a.rstride = Win * Cin;
   }
+  // taps that reach the input map for at least one output pixel
+  a.ntv = 0;
+  for (int t = 0; t < a.taps && t < 64; ++t) {
+    bool any = mode != RN_MODE_FWD;
+    if (!any) {
+      const int ky = t / kw, kx = t % kw;
+      bool anyy = false, anyx = false;
+      for (int o = 0; o < Hout; ++o) anyy |= (o * stride + ky - pad >= 0 && o * stride + ky - pad < Hin);
+      for (int o = 0; o < Wout; ++o) anyx |= (o * stride + kx - pad >= 0 && o * stride + kx - pad < Win);
+      any = anyy && anyx;
+    }
+    a.tapinv[t] = any ? (signed char)a.ntv : (signed char)-1;
+    if (any) a.tapv[a.ntv++] = (unsigned char)t;
+  }
+  if (a.taps > 64 || a.ntv < 1) return CRW_EINVAL;
   a.S = 1;
   a.S = rn_wgrad_slices(a);
   return CRW_OK;
@@ -102,7 +117,7 @@ static int wgrad_args(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin
 size_t crw_rn_wgrad_ws_bytes(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad) {
   RnWgradArgs a;
   if (wgrad_args(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad) != CRW_OK) return 0;
-  return (size_t)a.S * a.taps * a.Mtot * a.Ntot * 4;
+  return (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4;
 }
 
 int crw_rn_wgrad(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad,
@@ -112,7 +127,7 @@ int crw_rn_wgrad(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout,
   RnWgradArgs a;
   CRW_TRY(wgrad_args(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad));
   if (!x_hi || !x_lo || !d_hi || !d_lo || !dw || !ws) return CRW_EINVAL;
-  if (ws_bytes < (size_t)a.S * a.taps * a.Mtot * a.Ntot * 4) return CRW_EWORKSPACE;
+  if (ws_bytes < (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4) return CRW_EWORKSPACE;
   a.x_hi = x_hi; a.x_lo = x_lo; a.d_hi = d_hi; a.d_lo = d_lo;
   a.slab = (float *)ws;
   return launch_rn_wgrad(a, dw, (hipStream_t)stream);

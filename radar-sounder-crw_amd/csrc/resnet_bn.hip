@@ -62,15 +62,27 @@ __device__ inline void load_mask8(const uint16_t *hi, bool (&m)[8]) {
 }
 
 // ------------------------------------------------------------------------------------------------ two-level column sums
-// in [R][W] fp32 -> out [ceil(R / RB)][W] double: block row r2 adds rows [r2*RB, (r2+1)*RB) in order
-__global__ __launch_bounds__(256) void rn_rows_reduce_kernel(const float *__restrict__ in, int R, int W, int RB,
-                                                             double *__restrict__ out) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  if (w >= W) return;
+// in [R][W] fp32 -> out [ceil(R / RB)][W] double: block row r2 adds rows [r2*RB, (r2+1)*RB); block = 64 columns x 16 row lanes
+// (lane l takes rows l, l+16, ...; the 16 lane sums are added in lane order): fixed order, 16 rows in flight per column
+__global__ __launch_bounds__(1024) void rn_rows_reduce_kernel(const float *__restrict__ in, int R, int W, int RB,
+                                                              double *__restrict__ out) {
+  __shared__ double sh[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int w = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * RB, r1 = min(R, r0 + RB);
   double acc = 0.0;
-  for (int r = r0; r < r1; ++r) acc += (double)in[(long)r * W + w];
-  out[(long)blockIdx.y * W + w] = acc;
+  if (w < W) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 16) acc += (double)in[(long)r * W + w];
+  }
+  sh[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && w < W) {
+    double tot = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) tot += sh[l][cl];
+    out[(long)blockIdx.y * W + w] = tot;
+  }
 }
 
 // sum of the R2 rows of part2 [R2][W] at column w, by the 4 row lanes of a 64-column block (fixed order)
@@ -676,9 +688,11 @@ inline unsigned grid_for(long n, int per_block = 256, long cap = 8192) {
 
 // in [R][W] fp32 -> ws (doubles) [R2][W]; returns R2
 int rn_rows_reduce(const float *in, int R, int W, double *ws, hipStream_t s) {
-  const int RB = (R + 63) / 64 > 0 ? (R + 63) / 64 : 1;
+  // 32 block rows for wide inputs; narrow ones (the stem's 8 / 16 columns) get 64 so that more than a handful of blocks run
+  const int want = W >= 256 ? 32 : 64;
+  const int RB = (R + want - 1) / want > 0 ? (R + want - 1) / want : 1;
   const int R2 = (R + RB - 1) / RB;
-  hipLaunchKernelGGL(rn_rows_reduce_kernel, dim3((W + 255) / 256, R2), dim3(256), 0, s, in, R, W, RB, ws);
+  hipLaunchKernelGGL(rn_rows_reduce_kernel, dim3((W + 63) / 64, R2), dim3(1024), 0, s, in, R, W, RB, ws);
   return R2;
 }
 

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mtiles = a.Mtot / TM, ntiles = a.Ntot / TN;
   const int lin = blockIdx.x;
-  const int tap = lin / (mtiles * ntiles), mt = (lin / ntiles) % mtiles, nt = lin % ntiles;
+  const int tv = lin / (mtiles * ntiles), mt = (lin / ntiles) % mtiles, nt = lin % ntiles;
+  const int tap = a.tapv[tv];
   const int slice = blockIdx.y;
 
   if (wave == 0) rn_pairs(a, tap, lane, pa, pb, hdr);
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
     }
   }
 
-  float *slab = a.slab + ((long)slice * a.taps + tap) * a.Mtot * a.Ntot;
+  float *slab = a.slab + ((long)slice * a.ntv + tv) * a.Mtot * a.Ntot;
 #pragma unroll
   for (int i = 0; i < C::FM; ++i)
 #pragma unroll
@@ -431,24 +432,34 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
       }
 }
 
-// dw (torch layout) = sum over slices of the slabs, in slice order
-//   conv:  dw[co][ci][tap] = sum_s slab[s][tap][ci][co]                      (Mtot = cin, Ntot = cout)
-//   stem:  dw[co][c][ky][kx] = sum_s slab[s][0][ky * 32 + kx * 4 + c][co]    (Mtot = 256, Ntot = 64, cin = 3, 7x7)
-__global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(const float *__restrict__ slab, int S, int taps, int Mtot, int Ntot,
-                                                              int stem, float *__restrict__ dw) {
-  const long per = (long)taps * Mtot * Ntot;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= per) return;
+// dw (torch layout) = sum over slices of the slabs; block = 64 outputs x 4 slice lanes (lane l adds slices l, l+4, ... in order,
+// then the four lane sums are added pairwise): fixed order.  Taps that never reach the input map get zeros.
+//   conv:  dw[co][ci][tap] = sum_s slab[s][tapinv[tap]][ci][co]                (Mtot = cin, Ntot = cout)
+//   stem:  dw[co][c][ky][kx] = sum_s slab[s][0][ky * 32 + kx * 4 + c][co]      (Mtot = 256, Ntot = 64, cin = 3, 7x7)
+__global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(RnWgradArgs a, int stem, float *__restrict__ dw) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long mn = (long)a.Mtot * a.Ntot, per_all = (long)a.taps * mn, per = (long)a.ntv * mn;
+  const long idx = (long)blockIdx.x * 64 + cl;  // over [taps][Mtot][Ntot]
+  const int tap = idx < per_all ? (int)(idx / mn) : 0;
+  const int tv = a.tapinv[tap];
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += slab[s * per + idx];
-  const int co = (int)(idx % Ntot);
-  const int r = (int)((idx / Ntot) % Mtot);
-  const int tap = (int)(idx / ((long)Ntot * Mtot));
+  if (idx < per_all && tv >= 0) {
+    const float *src = a.slab + (long)tv * mn + idx % mn;
+#pragma unroll 4
+    for (int s = sl; s < a.S; s += 4) acc += src[(long)s * per];
+  }
+  sh[sl][cl] = acc;
+  __syncthreads();
+  if (sl != 0 || idx >= per_all) return;
+  acc = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  const int co = (int)(idx % a.Ntot);
+  const int r = (int)((idx / a.Ntot) % a.Mtot);
   if (stem) {
     const int ky = r >> 5, kx = (r >> 2) & 7, c = r & 3;
     if (ky < 7 && kx < 7 && c < 3) dw[((co * 3 + c) * 7 + ky) * 7 + kx] = acc;
   } else {
-    dw[((long)co * Mtot + r) * taps + tap] = acc;
+    dw[((long)co * a.Mtot + r) * a.taps + tap] = acc;
   }
 }
 
@@ -464,7 +475,7 @@ int launch_wgrad_cfg(const RnWgradArgs &a, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN>), dim3(a.taps * (a.Mtot / TM) * (a.Ntot / TN), a.S), dim3(256), C::LDS, s, a);
+  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN>), dim3(a.ntv * (a.Mtot / TM) * (a.Ntot / TN), a.S), dim3(256), C::LDS, s, a);
   return check_launch();
 }
 
@@ -488,7 +499,7 @@ int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
 
 int rn_wgrad_slices(const RnWgradArgs &a) {
   const int tm = a.Mtot % 128 ? 64 : 128, tn = a.Ntot % 128 ? 64 : 128;
-  const int tiles = a.taps * (a.Mtot / tm) * (a.Ntot / tn);
+  const int tiles = a.ntv * (a.Mtot / tm) * (a.Ntot / tn);
   int S = (1024 + tiles - 1) / tiles;
   const long kt = (long)a.Hout * a.Wout * a.ktiles_p;  // k-tiles of a tap that sees every output pixel
   if (S > kt / 4) S = (int)(kt / 4);                   // at least four k-tiles per slice
@@ -507,8 +518,7 @@ int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s) {
   else st = launch_wgrad_cfg<64, 64>(a, s);
   if (st != CRW_OK) return st;
   const long per = (long)a.taps * a.Mtot * a.Ntot;
-  hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, a.slab, a.S, a.taps, a.Mtot,
-                     a.Ntot, a.mode == RN_MODE_STEM_FWD ? 1 : 0, dw);
+  hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, a, a.mode == RN_MODE_STEM_FWD ? 1 : 0, dw);
   return check_launch();
 }
 
