@@ -140,7 +140,8 @@ def _rn_pairs(Hin, Win, Hout, Wout, k, stride, pad):
 
 
 def resnet_event_kernels(ev, P, steps):
-    """roofline lines of the Resnet matrix-core kernels from the HIP events of the timed steps (crw_hip.rn_conv / rn_wgrad).
+    """roofline lines of the Resnet matrix-core kernels from the HIP events the native pass records around each of their launches
+    in the timed steps (crw_rn_timing_*; ev: geometry key -> list of ms).
     Algorithmic flops of a convolution pass = 2 * P * pairs * cin * cout with pairs = the (output pixel, tap) pairs whose tap lies
     inside the input map (multiplications by padding zeros are not counted: a 3x3 convolution on layer4's 1x1 map is 1 tap)."""
     import crw_hip
@@ -172,7 +173,7 @@ def resnet_event_kernels(ev, P, steps):
             else:
                 alg, ex = 2.0 * P * Hout * Wout * 147 * 64, 256.0 / 147.0
                 name = "rn_wgrad_kernel stem 7x7/2 (+ slab sum)"
-        kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
+        kms = sum(pairs) / len(pairs)  # ms of every timed launch (crw_rn_timing_read)
         out.append({"kernel": name, "bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
                     "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
                     "mfma_executed_tflops": alg * 3 * ex / (kms * 1e-3) / 1e12,
@@ -474,6 +475,8 @@ def main():
     torch.cuda.synchronize()
     if rank == 0 and not args.no_events:
         crw_hip.KERNEL_EVENTS = {}  # HIP events around every conv launch of the timed steps, on the launch stream
+        if args.model == 1 and getattr(enc, "hip_convs", None):
+            crw_hip.rn_timing(True)  # the Resnet pass is driven from native code: it records its own events (crw_rn_timing_*)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -505,8 +508,13 @@ def main():
                        "encoder_convs": args.convs if (args.model == 0 or args.convs == "torch") else "bf16x3 (resnet_hip)", "loss": final_loss},
         }
         kernels = []
-        if crw_hip.KERNEL_EVENTS and args.model == 1:
-            ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+        if args.model == 1 and not args.no_events and getattr(enc, "hip_convs", None):
+            crw_hip.KERNEL_EVENTS = None
+            ev = {}
+            for rec in crw_hip.rn_timing_read():
+                key = ("rn_conv" if rec.kind == 0 else "rn_wgrad", rec.mode, *list(rec.g), rec.k, rec.stride, rec.pad)
+                ev.setdefault(key, []).append(rec.ms)
+            crw_hip.rn_timing(False)
             kernels = resnet_event_kernels(ev, B * T * N, args.steps)
         if crw_hip.KERNEL_EVENTS:
             # per-kernel durations measured live over the timed region (HIP events on the launch stream)

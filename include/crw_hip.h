@@ -300,6 +300,33 @@ int crw_rn_split(const float *x, int P, int C, uint16_t *hi, uint16_t *lo, crw_s
 size_t crw_rn_colsum_ws_bytes(int C);
 int crw_rn_colsum(const float *x, int rows, int C, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
 
+/* The whole encoder from native code: one call runs every launch of the forward (backward) pass on one workspace -- what the
+ * host modules use (resnet_hip.py); the entry points above remain as the building blocks the tests exercise one by one.
+ * Patches x [P][cin][16][16] (cin = 1, or 2 with pos_embed).  prm / grads: the CRW_RN_NPARAM parameter tensors (gradients) in
+ * nn.Module.named_parameters() order -- fc0.weight, fc0.bias, bn0.weight, bn0.bias, model.conv1.weight, model.bn1.{weight,bias},
+ * model.layer{1..4}.0.{conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias [, downsample.0.weight,
+ * downsample.1.weight, downsample.1.bias]}, model.fc.weight, model.fc.bias; run_mean / run_var (NULL together: not updated): the
+ * CRW_RN_NBN BatchNorm buffers in module order (bn0, model.bn1, then per layer bn1, bn2 [, downsample.1]).
+ * ws: crw_rn_train_ws_bytes; crw_rn_train_bwd needs the workspace exactly as crw_rn_train_fwd left it (activations, statistics,
+ * packed weights) and the same x / prm.  out [P][128] fp32. */
+#define CRW_RN_NPARAM 42
+#define CRW_RN_NBN 13
+size_t crw_rn_train_ws_bytes(int P, int cin, int h, int w);
+int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
+                     float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
+int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *grads,
+                     void *ws, size_t ws_bytes, crw_stream_t stream);
+/* Diagnostic (bench.py's in-step roofline; the one stateful corner of the library, not thread-safe): while enabled, every
+ * matrix-core launch of crw_rn_train_fwd / _bwd is bracketed by two HIP events on the launch stream.  After synchronising the
+ * stream, crw_rn_timing_read fills up to `max` records in launch order and returns how many were taken; enable(…) resets.
+ * kind 0 = crw_rn_conv (g = Hs, Ws, Cs, Hd, Wd, N), kind 1 = crw_rn_wgrad incl. its slab sum (g = Hin, Win, Cin, Hout, Wout, Cout). */
+typedef struct {
+  int kind, mode, g[6], k, stride, pad;
+  float ms;
+} crw_rn_timing_rec;
+int crw_rn_timing_enable(int on);
+int crw_rn_timing_read(crw_rn_timing_rec *out, int max);
+
 /* bf16 matrix-core variant of the chain GEMM.  A, B fp32 [batch,n,n] (n multiple of 128) are first
  * converted into bf16 images inside `ws` (convert != 0; pass 0 to reuse the images of the previous
  * call, e.g. when timing the GEMM alone).  split = 1: plain bf16 operands; split = 3: hi/lo operand

@@ -95,6 +95,11 @@ SIGNATURES = {
     "crw_rn_split": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "crw_rn_colsum_ws_bytes": (_c_sz, [_c_int]),
     "crw_rn_colsum": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_sz, _p]),
+    "crw_rn_train_ws_bytes": (_c_sz, [_c_int] * 4),
+    "crw_rn_train_fwd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
+    "crw_rn_train_bwd": (_c_int, [_p, _p] + [_c_int] * 4 + [_p, _p, _p, _c_sz, _p]),
+    "crw_rn_timing_enable": (_c_int, [_c_int]),
+    "crw_rn_timing_read": (_c_int, [_p, _c_int]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_gemm_bf16": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_sz, _c_int, _p]),
 }
@@ -697,3 +702,61 @@ def rn_colsum(x):
     ws = _ws(nbytes, x.device)
     _check(lib().crw_rn_colsum(_dev(x, "x"), rows, C, _dev(out, "out"), _ptr(ws), nbytes, _stream()), "crw_rn_colsum")
     return out
+
+
+# ---- the whole encoder from native code (crw_rn_train_fwd / _bwd) ------------------------------------------------------------
+RN_NPARAM, RN_NBN = 42, 13
+
+
+class RnTimingRec(ctypes.Structure):
+    _fields_ = [("kind", _c_int), ("mode", _c_int), ("g", _c_int * 6), ("k", _c_int), ("stride", _c_int), ("pad", _c_int),
+                ("ms", _c_f)]
+
+
+def _ptr_array(tensors, n):
+    if len(tensors) != n:
+        raise RuntimeError(f"expected {n} tensors, got {len(tensors)}")
+    for t in tensors:
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("Resnet parameters / buffers must be contiguous float32 tensors on the MI355X")
+    return (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+
+
+def rn_train_fwd(x, params, run_mean, run_var, momentum, eps):
+    """x [P,cin,16,16]; params: the 42 parameter tensors in named_parameters() order; run_mean / run_var: the 13 BatchNorm buffer
+    pairs in module order (updated in place) -> (out [P,128], workspace kept for rn_train_bwd)."""
+    P, cin, h, w = x.shape
+    nbytes = lib().crw_rn_train_ws_bytes(P, cin, h, w)
+    if nbytes == 0:
+        raise RuntimeError(f"crw_rn_train_fwd: unsupported input {tuple(x.shape)}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(P, 128, dtype=torch.float32, device=x.device)
+    _check(lib().crw_rn_train_fwd(_dev(x, "x"), P, cin, h, w, _ptr_array(params, RN_NPARAM), _ptr_array(run_mean, RN_NBN),
+                                  _ptr_array(run_var, RN_NBN), float(momentum), float(eps), _dev(out, "out"), _ptr(ws), nbytes,
+                                  _stream()), "crw_rn_train_fwd")
+    return out, ws
+
+
+def rn_train_bwd(dout, x, params, ws):
+    """-> the 42 gradients (views of one flat buffer), in the order of `params`"""
+    P, cin, h, w = x.shape
+    sizes = [p.numel() for p in params]
+    starts, tot = [], 0
+    for n in sizes:
+        starts.append(tot)
+        tot += (n + 3) // 4 * 4  # 16-byte aligned views
+    flat = torch.empty(tot, dtype=torch.float32, device=x.device)
+    grads = [flat[o:o + n].view(p.shape) for o, n, p in zip(starts, sizes, params)]
+    _check(lib().crw_rn_train_bwd(_dev(dout, "dout"), _dev(x, "x"), P, cin, h, w, _ptr_array(params, RN_NPARAM),
+                                  _ptr_array(grads, RN_NPARAM), _ptr(ws), ws.numel(), _stream()), "crw_rn_train_bwd")
+    return grads
+
+
+def rn_timing(enable):
+    _check(lib().crw_rn_timing_enable(int(enable)), "crw_rn_timing_enable")
+
+
+def rn_timing_read(max_records=100000):
+    buf = (RnTimingRec * max_records)()
+    n = lib().crw_rn_timing_read(buf, max_records)
+    return [buf[i] for i in range(min(n, max_records))]

@@ -41,6 +41,12 @@ struct RnWgradArgs {
 int rn_wgrad_slices(const RnWgradArgs &a);
 int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s);
 
+// resnet.hip: launch geometry from the layer description
+int rn_padded(int P);
+int rn_make_conv(RnConvArgs &a, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int kh, int kw, int stride, int pad);
+int rn_make_wgrad(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride,
+                  int pad);
+
 // resnet_bn.hip ------------------------------------------------------------------------------------------------------------
 int launch_rn_bn_stats(const float *part, int R, int C, double count, const float *gamma, const float *beta, float *run_mean,
                        float *run_var, float momentum, float eps, float *coef, double *ws /* 64 * 2C doubles */, hipStream_t s);

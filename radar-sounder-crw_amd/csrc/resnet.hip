@@ -5,9 +5,12 @@
 using namespace crw;
 
 namespace {
-inline int padded(int P) { return round_up(P, 128); }
 inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
+namespace crw {
+int rn_padded(int P) { return round_up(P, 128); }
+}
+#define padded crw::rn_padded
 
 extern "C" {
 
@@ -36,16 +39,15 @@ size_t crw_rn_conv_part_floats(int P, int G, int N) {
   return (size_t)(padded(P) / 128) * 2 * G * N * 2;
 }
 
-int crw_rn_conv(int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int kh, int kw, int stride, int pad,
-                const uint16_t *a_hi, const uint16_t *a_lo, const uint16_t *b_hi, const uint16_t *b_lo, const float *bias, float *out,
-                float *part, crw_stream_t stream) {
-  clear_stale_error();
-  if (!a_hi || !a_lo || !b_hi || !b_lo || !out || P < 1 || Hs < 1 || Ws < 1 || Cs < 1 || Hd < 1 || Wd < 1 || N < 64 || N % 64 ||
-      kh < 1 || kw < 1 || stride < 1 || pad < 0 || mode < RN_MODE_FWD || mode > RN_MODE_STEM_BWD)
+}  // extern "C"
+
+namespace crw {
+// geometry of one launch of the gathered matrix product (pointers are filled in by the caller)
+int rn_make_conv(RnConvArgs &a, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int kh, int kw, int stride, int pad) {
+  if (P < 1 || Hs < 1 || Ws < 1 || Cs < 1 || Hd < 1 || Wd < 1 || N < 64 || N % 64 || kh < 1 || kw < 1 || stride < 1 || pad < 0 ||
+      mode < RN_MODE_FWD || mode > RN_MODE_STEM_BWD)
     return CRW_EINVAL;
-  if (!aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) || !aligned16(b_lo)) return CRW_EINVAL;
-  RnConvArgs a{};
-  a.a_hi = a_hi; a.a_lo = a_lo; a.b_hi = b_hi; a.b_lo = b_lo; a.out = out; a.part = part; a.bias = bias;
+  a = RnConvArgs{};
   a.mode = mode; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.N = N;
   a.KH = kh; a.KW = kw; a.S = stride; a.PAD = pad;
   a.mtiles = padded(P) / 128;
@@ -66,11 +68,29 @@ int crw_rn_conv(int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, 
     a.b_group_stride = (long)N * a.ldb;
   }
   a.ldc = a.G * N;
+  return CRW_OK;
+}
+}  // namespace crw
+
+extern "C" {
+
+int crw_rn_conv(int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int kh, int kw, int stride, int pad,
+                const uint16_t *a_hi, const uint16_t *a_lo, const uint16_t *b_hi, const uint16_t *b_lo, const float *bias, float *out,
+                float *part, crw_stream_t stream) {
+  clear_stale_error();
+  if (!a_hi || !a_lo || !b_hi || !b_lo || !out) return CRW_EINVAL;
+  if (!aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) || !aligned16(b_lo)) return CRW_EINVAL;
+  RnConvArgs a;
+  CRW_TRY(rn_make_conv(a, mode, P, Hs, Ws, Cs, Hd, Wd, N, kh, kw, stride, pad));
+  a.a_hi = a_hi; a.a_lo = a_lo; a.b_hi = b_hi; a.b_lo = b_lo; a.out = out; a.part = part; a.bias = bias;
   return launch_rn_conv(a, (hipStream_t)stream);
 }
 
-static int wgrad_args(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride,
-                      int pad) {
+}  // extern "C"
+
+namespace crw {
+int rn_make_wgrad(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride,
+                  int pad) {
   if (P < 1 || Hin < 1 || Win < 1 || Cin < 1 || Hout < 1 || Wout < 1 || Cout < 64 || Cout % 64 || kh < 1 || kw < 1 || stride < 1 ||
       pad < 0 || (mode != RN_MODE_FWD && mode != RN_MODE_STEM_FWD))
     return CRW_EINVAL;
@@ -113,10 +133,13 @@ static int wgrad_args(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin
   a.S = rn_wgrad_slices(a);
   return CRW_OK;
 }
+}  // namespace crw
+
+extern "C" {
 
 size_t crw_rn_wgrad_ws_bytes(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad) {
   RnWgradArgs a;
-  if (wgrad_args(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad) != CRW_OK) return 0;
+  if (rn_make_wgrad(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad) != CRW_OK) return 0;
   return (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4;
 }
 
@@ -125,7 +148,7 @@ int crw_rn_wgrad(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout,
                  size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
   RnWgradArgs a;
-  CRW_TRY(wgrad_args(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad));
+  CRW_TRY(rn_make_wgrad(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad));
   if (!x_hi || !x_lo || !d_hi || !d_lo || !dw || !ws) return CRW_EINVAL;
   if (ws_bytes < (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4) return CRW_EWORKSPACE;
   a.x_hi = x_hi; a.x_lo = x_lo; a.d_hi = d_hi; a.d_lo = d_lo;

@@ -288,9 +288,9 @@ int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
 // =============================================================================================== TN: weight gradients
 constexpr int RN_MAXPAIR = 128;
 
-template <int TM, int TN>
+template <int TM, int TN, int BK_>
 struct TNCfg {
-  static constexpr int BK = 64, WAVES = 4, FM = TM / 32, FN = TN / 32, NSTAGE = 2;
+  static constexpr int BK = BK_, WAVES = 4, FM = TM / 32, FN = TN / 32, NSTAGE = 2;
   static constexpr int IMG_A = TM * 2 * BK, IMG_B = TN * 2 * BK, STAGE = 2 * IMG_A + 2 * IMG_B;
   static constexpr int PA = TM * BK / 512 / WAVES, PB = TN * BK / 512 / WAVES;
   static constexpr int TABLE = 2 * RN_MAXPAIR * 4 + 16;
@@ -329,9 +329,9 @@ __device__ inline void rn_pairs(const RnWgradArgs &a, int tap, int tid, int *pa,
   if (tid == 0) hdr[0] = count;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK_>
 __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
-  using C = TNCfg<TM, TN>;
+  using C = TNCfg<TM, TN, BK_>;
   constexpr int BK = C::BK;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int *pa = reinterpret_cast<int *>(lds + C::NSTAGE * C::STAGE);
@@ -339,15 +339,17 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
   int *hdr = pb + RN_MAXPAIR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mtiles = a.Mtot / TM, ntiles = a.Ntot / TN;
-  const int lin = blockIdx.x;
+  // every (tap, tile) of a patch slice reads the same patches: one XCD takes whole slices, so its L2 serves the re-reads
+  const int per_slice = a.ntv * mtiles * ntiles;
+  const int work = xcd_linear(blockIdx.x, gridDim.x);
+  const int slice = work / per_slice, lin = work % per_slice;
   const int tv = lin / (mtiles * ntiles), mt = (lin / ntiles) % mtiles, nt = lin % ntiles;
   const int tap = a.tapv[tv];
-  const int slice = blockIdx.y;
 
   if (wave == 0) rn_pairs(a, tap, lane, pa, pb, hdr);
   __syncthreads();
   const int npairs = hdr[0];
-  const long kt_total = (long)npairs * a.ktiles_p;
+  const long kt_total = (long)npairs * a.ktiles_p * (64 / BK);
   const int kt0 = (int)(kt_total * slice / a.S), kt1 = (int)(kt_total * (slice + 1) / a.S);
 
   // staging constants: r-contiguous images, LPR lanes per k-row
@@ -356,8 +358,9 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
 
   auto stage = [&](int kt, int buf) {
     char *base = lds + buf * C::STAGE;
-    const int pair = kt / a.ktiles_p;
-    const int p0 = (kt - pair * a.ktiles_p) * BK;
+    const int ktp = a.ktiles_p * (64 / BK);  // k-tiles per pair
+    const int pair = kt / ktp;
+    const int p0 = (kt - pair * ktp) * BK;
     const int oa = pa[pair], ob = pb[pair];
 #pragma unroll
     for (int i = 0; i < C::PA; ++i) {
@@ -463,19 +466,19 @@ __global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(RnWgradArgs a, int
   }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK_>
 int launch_wgrad_cfg(const RnWgradArgs &a, hipStream_t s) {
-  using C = TNCfg<TM, TN>;
+  using C = TNCfg<TM, TN, BK_>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)rn_wgrad_kernel<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) !=
+    if (hipFuncSetAttribute((const void *)rn_wgrad_kernel<TM, TN, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) !=
         hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN>), dim3(a.ntv * (a.Mtot / TM) * (a.Ntot / TN), a.S), dim3(256), C::LDS, s, a);
+  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN, BK_>), dim3(a.ntv * (a.Mtot / TM) * (a.Ntot / TN) * a.S), dim3(256), C::LDS, s, a);
   return check_launch();
 }
 
@@ -484,8 +487,8 @@ int launch_wgrad_cfg(const RnWgradArgs &a, hipStream_t s) {
 int rn_conv_bk() {
   static int bk = -1;
   if (bk < 0) {
-    const char *e = getenv("CRW_RN_BK");  // A/B knob: 64 = one workgroup per CU, 32 = smaller stages, two per CU
-    bk = (e && atoi(e) == 32) ? 32 : 64;
+    const char *e = getenv("CRW_RN_BK");  // A/B knob: force the k-tile depth (64: two 64-deep stages; 32: three 32-deep stages)
+    bk = e ? atoi(e) : 0;
   }
   return bk;
 }
@@ -493,7 +496,13 @@ int rn_conv_bk() {
 int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
   if (a.N % 64 || a.mtiles < 1 || a.G < 1 || a.KH * a.KW > RN_MAXSEG) return CRW_EINVAL;
   const bool wide = a.N % 128 == 0;
-  if (rn_conv_bk() == 32) return wide ? launch_conv_cfg<128, 32, 3>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);
+  // measured in the training step (r03): the 64-column tiles (layer1, the stem forward) are 20 % faster on three 32-deep
+  // stages (72 KB of LDS: two workgroups per CU cover each other's short k-loops); the 128-column tiles and the long single
+  // segment of the stem's backward-data product prefer two 64-deep stages
+  int bk = rn_conv_bk();
+  if (bk != 32 && bk != 64 && bk != 322) bk = (wide || a.mode == RN_MODE_STEM_BWD) ? 64 : 32;
+  if (bk == 322) return wide ? launch_conv_cfg<128, 32, 2>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);  // A/B: wide tiles, two per CU
+  if (bk == 32) return wide ? launch_conv_cfg<128, 32, 3>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);
   return wide ? launch_conv_cfg<128, 64, 2>(a, s) : launch_conv_cfg<64, 64, 2>(a, s);
 }
 
@@ -511,11 +520,23 @@ int rn_wgrad_slices(const RnWgradArgs &a) {
 int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s) {
   if (a.Mtot % 64 || a.Ntot % 64 || a.Hout * a.Wout > RN_MAXPAIR || a.S < 1) return CRW_EINVAL;
   const bool m128 = a.Mtot % 128 == 0, n128 = a.Ntot % 128 == 0;
+  static int bk = -1;
+  if (bk < 0) {
+    const char *e = getenv("CRW_RN_WBK");  // A/B knob: patches per k-tile of the weight gradient (64: one workgroup per CU at 128 x 128)
+    bk = e ? atoi(e) : 0;
+  }
   int st;
-  if (m128 && n128) st = launch_wgrad_cfg<128, 128>(a, s);
-  else if (m128) st = launch_wgrad_cfg<128, 64>(a, s);
-  else if (n128) st = launch_wgrad_cfg<64, 128>(a, s);
-  else st = launch_wgrad_cfg<64, 64>(a, s);
+  if (bk == 32) {
+    if (m128 && n128) st = launch_wgrad_cfg<128, 128, 32>(a, s);
+    else if (m128) st = launch_wgrad_cfg<128, 64, 32>(a, s);
+    else if (n128) st = launch_wgrad_cfg<64, 128, 32>(a, s);
+    else st = launch_wgrad_cfg<64, 64, 32>(a, s);
+  } else {
+    if (m128 && n128) st = launch_wgrad_cfg<128, 128, 64>(a, s);
+    else if (m128) st = launch_wgrad_cfg<128, 64, 64>(a, s);
+    else if (n128) st = launch_wgrad_cfg<64, 128, 64>(a, s);
+    else st = launch_wgrad_cfg<64, 64, 64>(a, s);
+  }
   if (st != CRW_OK) return st;
   const long per = (long)a.taps * a.Mtot * a.Ntot;
   hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, a, a.mode == RN_MODE_STEM_FWD ? 1 : 0, dw);

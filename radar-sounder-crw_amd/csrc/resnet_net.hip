@@ -1,0 +1,333 @@
+// The whole Resnet encoder (reference src/encoder.py:63-89,109-155,157-272) as TWO entry points: crw_rn_train_fwd and
+// crw_rn_train_bwd run every launch of the forward / backward pass from native code on one caller-provided workspace
+// (~230 launches per training step: driven from Python, one ctypes call and a handful of tensor allocations per launch, the
+// step was host-bound at ~8.9 ms; the kernels themselves take ~7).  The schedule is the one documented in resnet_hip.py.
+#include <vector>
+
+#include "resnet.h"
+
+using namespace crw;
+
+namespace {
+
+constexpr int NPARAM = 42, NBN = 13, FEAT = 128;
+
+struct Blk {
+  int cin, cout, stride, hin, win, hout, wout, down;
+  int pbase;  // index of conv1.weight in the parameter list
+  int bn;     // index of bn1 in the running-statistics lists (bn2 = +1, shortcut = +2)
+};
+
+struct Planes {
+  uint16_t *hi, *lo;
+};
+struct Wpack {
+  uint16_t *fh, *fl, *bh, *bl;
+};
+
+// every buffer of a step at a fixed offset of the workspace (the same function sizes it, with base = nullptr)
+struct Plan {
+  int P, Ppad, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm, ldt;
+  Blk blk[4];
+  char *base;
+  size_t off = 0;
+  bool ok = true;
+
+  template <typename T>
+  T *take(size_t n) {
+    off = align_up(off, 256);
+    T *p = reinterpret_cast<T *>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+  Planes planes(size_t n) { return Planes{take<uint16_t>(n), take<uint16_t>(n)}; }
+  Wpack wpack(size_t n) { return Wpack{take<uint16_t>(n), take<uint16_t>(n), take<uint16_t>(n), take<uint16_t>(n)}; }
+
+  // forward (kept for the backward)
+  float *stem;
+  uint16_t *wsf_h, *wsf_l, *wst_h, *wst_l;
+  Planes xmap, A1;
+  float *Z1, *coef1;
+  struct {
+    Wpack wa, wb, wd;
+    float *Za, *Zb, *Zd, *ca, *cb, *cd;
+    Planes Aa, Aout;
+  } r[4];
+  Wpack wfc;
+  float *outp;  // [Ppad][128]
+  // scratch
+  float *part;
+  double *stats_ws;
+  void *stem_ws;
+  Planes dO, dzb, dza, dzd, dz1;
+  float *g[4], *gA, *dX0;
+  void *wgrad_ws, *bnbwd_ws, *poolbwd_ws, *colsum_ws;
+  size_t wgrad_bytes = 0;
+
+  static int outdim(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+  Plan(int P_, int cin_, int h_, int w_, void *ws) : P(P_), cin(cin_), h(h_), w(w_), base((char *)ws) {
+    Ppad = rn_padded(P);
+    H0 = h + 2; W0 = w + 2;
+    H1 = outdim(H0, 7, 2, 3); W1 = outdim(W0, 7, 2, 3);
+    H2 = outdim(H1, 3, 2, 1); W2 = outdim(W1, 3, 2, 1);
+    Hm = std::max(H0 + 6, 2 * H1 + 6); Wm = std::max(W0 + 6, 2 * W1 + 6);
+    ldt = 4 * W1 * 64;
+    const int couts[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 2, 2}, pbase[4] = {7, 13, 22, 31}, bnidx[4] = {2, 4, 7, 10};
+    int hh = H2, ww = W2, c = 64;
+    for (int i = 0; i < 4; ++i) {
+      Blk &b = blk[i];
+      b.cin = c; b.cout = couts[i]; b.stride = strides[i]; b.hin = hh; b.win = ww;
+      b.hout = outdim(hh, 3, b.stride, 1); b.wout = outdim(ww, 3, b.stride, 1);
+      b.down = (b.stride != 1 || b.cin != b.cout);
+      b.pbase = pbase[i]; b.bn = bnidx[i];
+      hh = b.hout; ww = b.wout; c = b.cout;
+    }
+    // the kernels of this build cover the 16 x 16 patches of the reference's defaults: 9 x 9 map after the stem, 1 x 1 at the head
+    if (hh != 1 || ww != 1 || H1 != 9 || W1 != 9 || 3 * W0 > 64 || cin < 1 || cin > 2) ok = false;
+    if (!ok) return;
+    const size_t pp = (size_t)Ppad;
+    stem = take<float>(32);
+    wsf_h = take<uint16_t>(64 * 256); wsf_l = take<uint16_t>(64 * 256);
+    wst_h = take<uint16_t>((size_t)H0 * 64 * ldt); wst_l = take<uint16_t>((size_t)H0 * 64 * ldt);
+    xmap = planes(pp * Hm * Wm * 4);
+    Z1 = take<float>(pp * H1 * W1 * 64);
+    coef1 = take<float>(4 * 64);
+    A1 = planes(pp * H2 * W2 * 64);
+    size_t gmax = pp * H2 * W2 * 64, part_max = crw_rn_conv_part_floats(P, H1 * W1, 64);
+    for (int i = 0; i < 4; ++i) {
+      const Blk &b = blk[i];
+      const size_t n = pp * b.hout * b.wout * b.cout;
+      r[i].wa = wpack((size_t)b.cout * b.cin * 9);
+      r[i].wb = wpack((size_t)b.cout * b.cout * 9);
+      r[i].wd = b.down ? wpack((size_t)b.cout * b.cin) : Wpack{};
+      r[i].Za = take<float>(n); r[i].Zb = take<float>(n); r[i].Zd = b.down ? take<float>(n) : nullptr;
+      r[i].ca = take<float>(4 * b.cout); r[i].cb = take<float>(4 * b.cout); r[i].cd = b.down ? take<float>(4 * b.cout) : nullptr;
+      r[i].Aa = planes(n); r[i].Aout = planes(n);
+      gmax = std::max(gmax, std::max(n, pp * b.hin * b.win * b.cin));
+      part_max = std::max(part_max, crw_rn_conv_part_floats(P, b.hout * b.wout, b.cout));
+    }
+    wfc = wpack((size_t)FEAT * 512);
+    outp = take<float>(pp * FEAT);
+    part = take<float>(part_max);
+    stats_ws = take<double>((size_t)64 * 2 * 512);
+    stem_ws = take<char>(rn_stem_ws_bytes());
+    dO = planes(pp * FEAT);
+    dzb = planes(gmax); dza = planes(gmax); dzd = planes(gmax);
+    dz1 = planes(pp * H1 * W1 * 64);
+    for (int i = 0; i < 4; ++i) g[i] = take<float>(gmax);
+    gA = take<float>(gmax);
+    dX0 = take<float>(pp * H0 * 64);
+    // weight-gradient slabs: the largest of any layer
+    auto need = [&](int mode, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int k, int s, int pad) {
+      RnWgradArgs a;
+      if (rn_make_wgrad(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, k, k, s, pad) != CRW_OK) { ok = false; return; }
+      wgrad_bytes = std::max(wgrad_bytes, (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4);
+    };
+    need(RN_MODE_STEM_FWD, Hm, Wm, 4, H1, W1, 64, 7, 2, 3);
+    need(RN_MODE_FWD, 1, 1, 512, 1, 1, FEAT, 1, 1, 0);
+    size_t bnb = 0;
+    for (int i = 0; i < 4; ++i) {
+      const Blk &b = blk[i];
+      need(RN_MODE_FWD, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1);
+      need(RN_MODE_FWD, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1);
+      if (b.down) need(RN_MODE_FWD, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0);
+      bnb = std::max(bnb, rn_bn_bwd_ws_bytes(P, b.hout * b.wout, b.cout));
+    }
+    wgrad_ws = take<char>(wgrad_bytes);
+    bnbwd_ws = take<char>(bnb);
+    poolbwd_ws = take<char>(rn_pool_bwd_ws_bytes(P, 64));
+    colsum_ws = take<char>(rn_colsum_ws_bytes(FEAT));
+    off = align_up(off, 256);
+  }
+};
+
+// ---- optional in-step timing: two HIP events around every matrix-core launch, on the launch stream ------------------------
+struct TimingState {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<crw_rn_timing_rec> recs;
+  size_t used = 0;
+} g_tm;
+
+struct Timed {
+  hipStream_t s;
+  bool live;
+  size_t idx;
+  Timed(hipStream_t s_, int kind, int mode, int a, int b, int c, int d, int e, int f, int k, int st, int pad) : s(s_), live(g_tm.on) {
+    if (!live) return;
+    if (g_tm.used + 2 > g_tm.pool.size()) {
+      for (int i = 0; i < 64; ++i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) { live = false; return; }
+        g_tm.pool.push_back(ev);
+      }
+    }
+    idx = g_tm.used;
+    g_tm.used += 2;
+    g_tm.recs.push_back(crw_rn_timing_rec{kind, mode, {a, b, c, d, e, f}, k, st, pad, 0.f});
+    (void)hipEventRecord(g_tm.pool[idx], s);
+  }
+  ~Timed() {
+    if (live) (void)hipEventRecord(g_tm.pool[idx + 1], s);
+  }
+};
+
+int conv(hipStream_t s, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int k, int stride, int pad, Planes a, const uint16_t *bh,
+         const uint16_t *bl, const float *bias, float *out, float *part) {
+  RnConvArgs q;
+  CRW_TRY(rn_make_conv(q, mode, P, Hs, Ws, Cs, Hd, Wd, N, k, k, stride, pad));
+  q.a_hi = a.hi; q.a_lo = a.lo; q.b_hi = bh; q.b_lo = bl; q.out = out; q.part = part; q.bias = bias;
+  Timed t(s, 0, mode, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad);
+  return launch_rn_conv(q, s);
+}
+
+int wgrad(hipStream_t s, int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int pad, Planes x,
+          Planes d, float *dw, void *ws) {
+  RnWgradArgs q;
+  CRW_TRY(rn_make_wgrad(q, mode, P, Hin, Win, Cin, Hout, Wout, Cout, k, k, stride, pad));
+  q.x_hi = x.hi; q.x_lo = x.lo; q.d_hi = d.hi; q.d_lo = d.lo;
+  q.slab = (float *)ws;
+  Timed t(s, 1, mode, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad);
+  return launch_rn_wgrad(q, dw, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t crw_rn_train_ws_bytes(int P, int cin, int h, int w) {
+  if (P < 1) return 0;
+  Plan pl(P, cin, h, w, nullptr);
+  return pl.ok ? pl.off : 0;
+}
+
+int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
+                     float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !prm || !out || !ws || P < 1 || (run_mean == nullptr) != (run_var == nullptr)) return CRW_EINVAL;
+  for (int i = 0; i < NPARAM; ++i)
+    if (!prm[i]) return CRW_EINVAL;
+  Plan pl(P, cin, h, w, ws);
+  if (!pl.ok) return CRW_EINVAL;
+  if (ws_bytes < pl.off) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  auto rm = [&](int i) { return run_mean ? run_mean[i] : nullptr; };
+  auto rv = [&](int i) { return run_var ? run_var[i] : nullptr; };
+
+  // stem: fc0 + bn0 + relu0 -> 4-channel map; 7x7/2 convolution + statistics; bn1 + relu + max-pool
+  CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, s));
+  CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
+                             pl.xmap.lo, pl.stem, pl.stem_ws, s));
+  CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1, pl.part));
+  CRW_TRY(launch_rn_bn_stats(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1),
+                             momentum, eps, pl.coef1, pl.stats_ws, s));
+  CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, s));
+
+  Planes A = pl.A1;
+  for (int i = 0; i < 4; ++i) {
+    const Blk &b = pl.blk[i];
+    auto &r = pl.r[i];
+    const int npix = b.hout * b.wout, rows = (pl.Ppad / 128) * 2 * npix;
+    const double cnt = (double)P * npix;
+    const float *const *q = prm + b.pbase;
+    CRW_TRY(launch_rn_pack_conv(q[0], b.cout, b.cin, 9, r.wa.fh, r.wa.fl, r.wa.bh, r.wa.bl, s));
+    CRW_TRY(launch_rn_pack_conv(q[3], b.cout, b.cout, 9, r.wb.fh, r.wb.fl, r.wb.bh, r.wb.bl, s));
+    CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, A, r.wa.fh, r.wa.fl, nullptr, r.Za, pl.part));
+    CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[1], q[2], rm(b.bn), rv(b.bn), momentum, eps, r.ca, pl.stats_ws, s));
+    CRW_TRY(launch_rn_bn_apply(r.Za, r.ca, nullptr, nullptr, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aa.hi, r.Aa.lo, s));
+    CRW_TRY(conv(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, r.wb.fh, r.wb.fl, nullptr, r.Zb, pl.part));
+    CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[4], q[5], rm(b.bn + 1), rv(b.bn + 1), momentum, eps, r.cb, pl.stats_ws, s));
+    if (b.down) {
+      CRW_TRY(launch_rn_pack_conv(q[6], b.cout, b.cin, 1, r.wd.fh, r.wd.fl, r.wd.bh, r.wd.bl, s));
+      CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, A, r.wd.fh, r.wd.fl, nullptr, r.Zd, pl.part));
+      CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[7], q[8], rm(b.bn + 2), rv(b.bn + 2), momentum, eps, r.cd, pl.stats_ws, s));
+      CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, r.Zd, r.cd, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
+    } else {
+      CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, nullptr, nullptr, A.hi, A.lo, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
+    }
+    A = r.Aout;
+  }
+  // head: the average pool of the 1 x 1 map is the identity; linear 512 -> 128 with bias
+  CRW_TRY(launch_rn_pack_conv(prm[40], FEAT, 512, 1, pl.wfc.fh, pl.wfc.fl, pl.wfc.bh, pl.wfc.bl, s));
+  CRW_TRY(conv(s, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, A, pl.wfc.fh, pl.wfc.fl, prm[41], pl.outp, nullptr));
+  if (hipMemcpyAsync(out, pl.outp, (size_t)P * FEAT * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    g_last_hip_error = (int)hipGetLastError();
+    return CRW_EHIP;
+  }
+  return CRW_OK;
+}
+
+int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *grads,
+                     void *ws, size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!dout || !x || !prm || !grads || !ws || P < 1) return CRW_EINVAL;
+  for (int i = 0; i < NPARAM; ++i)
+    if (!prm[i] || !grads[i]) return CRW_EINVAL;
+  Plan pl(P, cin, h, w, ws);
+  if (!pl.ok) return CRW_EINVAL;
+  if (ws_bytes < pl.off) return CRW_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+
+  // head
+  CRW_TRY(launch_rn_split(dout, P, pl.Ppad, FEAT, pl.dO.hi, pl.dO.lo, s));
+  CRW_TRY(wgrad(s, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, pl.r[3].Aout, pl.dO, grads[40], pl.wgrad_ws));
+  CRW_TRY(launch_rn_colsum(dout, P, FEAT, grads[41], pl.colsum_ws, s));
+  float *g1 = pl.g[0], *g2 = nullptr;
+  CRW_TRY(conv(s, RN_MODE_BWD, P, 1, 1, FEAT, 1, 1, 512, 1, 1, 0, pl.dO, pl.wfc.bh, pl.wfc.bl, nullptr, g1, nullptr));
+  int flip = 0;  // g[0], g[1] hold the gradient of the current block's output; g[2], g[3] receive the one of its input
+  for (int i = 3; i >= 0; --i) {
+    const Blk &b = pl.blk[i];
+    auto &r = pl.r[i];
+    const int npix = b.hout * b.wout;
+    float *const *gq = grads + b.pbase;
+    float *n1 = pl.g[flip ? 0 : 2], *n2 = pl.g[flip ? 1 : 3];
+    const Planes Ain = i == 0 ? pl.A1 : pl.r[i - 1].Aout;
+    CRW_TRY(launch_rn_bn_bwd(g1, g2, r.Aout.hi, r.Zb, r.cb, r.Zd, r.cd, P, pl.Ppad, npix, b.cout, pl.dzb.hi, pl.dzb.lo, b.down ? pl.dzd.hi : nullptr,
+                             b.down ? pl.dzd.lo : nullptr, b.down ? nullptr : n2, gq[4], gq[5], b.down ? gq[7] : nullptr,
+                             b.down ? gq[8] : nullptr, pl.bnbwd_ws, s));
+    CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, pl.dzb, gq[3], pl.wgrad_ws));
+    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, pl.dzb, r.wb.bh, r.wb.bl, nullptr, pl.gA, nullptr));
+    CRW_TRY(launch_rn_bn_bwd(pl.gA, nullptr, r.Aa.hi, r.Za, r.ca, nullptr, nullptr, P, pl.Ppad, npix, b.cout, pl.dza.hi, pl.dza.lo, nullptr, nullptr,
+                             nullptr, gq[1], gq[2], nullptr, nullptr, pl.bnbwd_ws, s));
+    CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, Ain, pl.dza, gq[0], pl.wgrad_ws));
+    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza, r.wa.bh, r.wa.bl, nullptr, n1, nullptr));
+    if (b.down) {
+      CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, Ain, pl.dzd, gq[6], pl.wgrad_ws));
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 1, b.stride, 0, pl.dzd, r.wd.bh, r.wd.bl, nullptr, n2, nullptr));
+    }
+    g1 = n1;
+    g2 = n2;
+    flip ^= 1;
+  }
+  // max-pool + bn1, stem convolution, stem
+  CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
+  CRW_TRY(wgrad(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.dz1, grads[4], pl.wgrad_ws));
+  CRW_TRY(conv(s, RN_MODE_STEM_BWD, P, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3, pl.dz1, pl.wst_h, pl.wst_l, nullptr, pl.dX0, nullptr));
+  CRW_TRY(launch_rn_stem_bwd(pl.dX0, x, pl.stem, prm[0], prm[1], P, cin, h, w, 64, grads[0], grads[1], grads[2], grads[3], pl.stem_ws, s));
+  return CRW_OK;
+}
+
+int crw_rn_timing_enable(int on) {
+  g_tm.on = on != 0;
+  g_tm.used = 0;
+  g_tm.recs.clear();
+  return CRW_OK;
+}
+
+int crw_rn_timing_read(crw_rn_timing_rec *out, int max) {
+  const int n = (int)std::min<size_t>(g_tm.recs.size(), max > 0 ? (size_t)max : 0);
+  for (int i = 0; i < n; ++i) {
+    crw_rn_timing_rec rec = g_tm.recs[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_tm.pool[2 * i], g_tm.pool[2 * i + 1]) != hipSuccess) {
+      (void)hipGetLastError();
+      ms = -1.f;
+    }
+    rec.ms = ms;
+    out[i] = rec;
+  }
+  return (int)g_tm.recs.size();
+}
+
+}  // extern "C"

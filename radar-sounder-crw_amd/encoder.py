@@ -285,13 +285,16 @@ class Resnet(nn.Module):
         self.relu0 = nn.ReLU(inplace=True)
         self.model = _ResNetBody(FEATURE_DIM)
         self.num_params = _report(self)
-        self.hip_convs = "bf16x3"  # "bf16x3" (hi/lo bf16 operand pairs, fp32-grade) | None (PyTorch ops)
+        # "bf16x3": hi/lo bf16 operand pairs (fp32-grade), the whole pass driven from native code; "stepwise": the same kernels
+        # launched one by one from Python (tests); None: PyTorch ops
+        self.hip_convs = "bf16x3"
 
     def forward(self, x):
         if self.hip_convs and x.is_cuda:
             import resnet_hip
             if resnet_hip.supported(x, self):
-                return resnet_hip.HipResnetFn.apply(x, self, *self.parameters())
+                fn = resnet_hip.HipResnetFn if self.hip_convs == "stepwise" else resnet_hip.HipResnetNative
+                return fn.apply(x, self, *self.parameters())
             if not Resnet._warned_fallback:
                 Resnet._warned_fallback = True
                 warnings.warn(f"Resnet.forward: input {tuple(x.shape)} {x.dtype} (training: {self.training}) is not covered by the HIP "

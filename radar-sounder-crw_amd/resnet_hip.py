@@ -40,6 +40,34 @@ class _Block:
         self.hout, self.wout = _out(hin, 3, self.stride, 1), _out(win, 3, self.stride, 1)
 
 
+def _bn_modules(net):
+    return [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+
+
+class HipResnetNative(torch.autograd.Function):
+    """The training path: crw_rn_train_fwd / crw_rn_train_bwd run the schedule above from native code on one workspace (driven
+    launch by launch from Python -- ``HipResnetFn`` below, which the tests keep as the readable statement of the schedule -- the
+    ~230 launches of a step make the step host-bound)."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        x = x.contiguous()
+        bns = _bn_modules(net)
+        prm = [p.detach() for p in params]
+        out, ws = H.rn_train_fwd(x, prm, [m.running_mean for m in bns], [m.running_var for m in bns], net.bn0.momentum, net.bn0.eps)
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        ctx.x, ctx.ws, ctx.prm = x, ws, prm
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("the HIP Resnet path does not produce a gradient for its input patches (the reference never asks for one)")
+        grads = H.rn_train_bwd(dout.contiguous().float(), ctx.x, ctx.prm, ctx.ws)
+        ctx.ws = None
+        return (None, None) + tuple(grads)
+
+
 class HipResnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, *params):
