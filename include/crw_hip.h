@@ -269,8 +269,11 @@ int crw_rn_bn_stats(const float *part, int P, int G, int C, const float *gamma, 
 /* y planes = relu?( Z * scale + shift [+ Zd * scale_d + shift_d] [+ residual planes] )   (src/encoder.py:138-153) */
 int crw_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
                     const uint16_t *res_lo, int P, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream);
-/* y planes [Ppad][Ho*Wo][C] = maxpool3x3/2/1( relu( Z * scale + shift ) ), Z on an H x W map   (src/encoder.py:257-260) */
-int crw_rn_bn_pool(const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream);
+/* y planes [Ppad][Ho*Wo][C] = maxpool3x3/2/1( relu( Z * scale + shift ) ), Z on an H x W map   (src/encoder.py:257-260);
+ * amax (may be NULL; [Ppad][Ho*Wo][C] bytes): position ky * 3 + kx of the first maximum of every window (ATen's rule), for the
+ * backward pass */
+int crw_rn_bn_pool(const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo, uint8_t *amax,
+                   crw_stream_t stream);
 /* backward of y = relu(bn(Z) [+ bn_d(Zd)] [+ identity]): g = (g1 [+ g2]) where mask_hi (the hi plane of y) is non-zero;
  * dz planes = gradient of Z, dzd planes = gradient of Zd, g_out (may be NULL) = g in fp32 (the identity shortcut's share),
  * dgamma / dbeta [C] (and the shortcut BatchNorm's). */
@@ -279,11 +282,11 @@ int crw_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, con
                   const float *coef_d, int P, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi, uint16_t *dzd_lo,
                   float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws, size_t ws_bytes,
                   crw_stream_t stream);
-/* backward of crw_rn_bn_pool: d1 (+ d2) = gradient of the pooled map [Ppad][25][C] fp32 -> dz planes [Ppad][81][C] (9 x 9 maps:
- * 16 x 16 patches), dgamma / dbeta of that BatchNorm */
-size_t crw_rn_pool_bwd_ws_bytes(int P, int C);
-int crw_rn_pool_bwd(const float *d1, const float *d2, const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *dz_hi,
-                    uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* backward of crw_rn_bn_pool: d1 (+ d2, may be NULL) = gradient of the pooled map [Ppad][Ho*Wo][C] fp32, amax = the codes the
+ * forward recorded -> dz planes [Ppad][H*W][C], dgamma / dbeta of that BatchNorm */
+size_t crw_rn_pool_bwd_ws_bytes(int P, int H, int W, int C);
+int crw_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int H, int W, int C,
+                    uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream);
 /* stem: relu0(bn0(fc0(x))) with fc0 = Conv2d(cin, 3, 1, padding 1) (src/encoder.py:66-74,87): x [P][cin][h][w] -> the map planes
  * [Ppad][Hm][Wm][4] that feed the stem convolution (the (h+2) x (w+2) map at offset (3,3), zero elsewhere, channel 3 = 0);
  * bn0's batch statistics follow from the moments of x.  stem [32] floats = the record crw_rn_stem_bwd needs. */

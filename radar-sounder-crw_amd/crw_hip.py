@@ -84,11 +84,11 @@ SIGNATURES = {
     "crw_rn_bn_stats_ws_bytes": (_c_sz, [_c_int]),
     "crw_rn_bn_stats": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
     "crw_rn_bn_apply": (_c_int, [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "crw_rn_bn_pool": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_rn_bn_pool": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "crw_rn_bn_bwd_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "crw_rn_bn_bwd": (_c_int, [_p] * 7 + [_c_int] * 3 + [_p] * 10 + [_c_sz, _p]),
-    "crw_rn_pool_bwd_ws_bytes": (_c_sz, [_c_int, _c_int]),
-    "crw_rn_pool_bwd": (_c_int, [_p] * 4 + [_c_int] * 4 + [_p] * 5 + [_c_sz, _p]),
+    "crw_rn_pool_bwd_ws_bytes": (_c_sz, [_c_int] * 4),
+    "crw_rn_pool_bwd": (_c_int, [_p] * 5 + [_c_int] * 4 + [_p] * 5 + [_c_sz, _p]),
     "crw_rn_stem_ws_bytes": (_c_sz, []),
     "crw_rn_stem_fwd": (_c_int, [_p] + [_c_int] * 6 + [_p] * 6 + [_c_f, _c_f] + [_p] * 4 + [_c_sz, _p]),
     "crw_rn_stem_bwd": (_c_int, [_p] * 5 + [_c_int] * 4 + [_p] * 5 + [_c_sz, _p]),
@@ -617,9 +617,10 @@ def rn_bn_pool(Z, coef, P, H, W, C):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     yh = torch.empty(Ppad, Ho * Wo * C, dtype=_BF, device=Z.device)
     yl = torch.empty_like(yh)
-    _check(lib().crw_rn_bn_pool(_dev(Z, "Z"), _dev(coef, "coef"), P, H, W, C, _bf(yh, "yh"), _bf(yl, "yl"), _stream()),
+    amax = torch.empty(Ppad, Ho * Wo * C, dtype=torch.uint8, device=Z.device)
+    _check(lib().crw_rn_bn_pool(_dev(Z, "Z"), _dev(coef, "coef"), P, H, W, C, _bf(yh, "yh"), _bf(yl, "yl"), _ptr(amax), _stream()),
            "crw_rn_bn_pool")
-    return yh, yl
+    return (yh, yl), amax
 
 
 def rn_bn_bwd(g1, g2, mask_hi, Z, coef, P, npix, C, Zd=None, coef_d=None, want_g=False):
@@ -641,16 +642,16 @@ def rn_bn_bwd(g1, g2, mask_hi, Z, coef, P, npix, C, Zd=None, coef_d=None, want_g
     return (dzh, dzl), ((dzdh, dzdl) if Zd is not None else None), gout, dg, db, dgd, dbd
 
 
-def rn_pool_bwd(d1, d2, Z, coef, P, H, W, C):
+def rn_pool_bwd(d1, d2, amax, Z, coef, P, H, W, C):
     Ppad = rn_padded(P)
     dev = Z.device
     dzh = torch.empty(Ppad, H * W * C, dtype=_BF, device=dev)
     dzl = torch.empty_like(dzh)
     dg = torch.empty(C, dtype=torch.float32, device=dev)
     db = torch.empty_like(dg)
-    nbytes = lib().crw_rn_pool_bwd_ws_bytes(P, C)
+    nbytes = lib().crw_rn_pool_bwd_ws_bytes(P, H, W, C)
     ws = _ws(nbytes, dev)
-    _check(lib().crw_rn_pool_bwd(_dev(d1, "d1"), _ptr(d2), _dev(Z, "Z"), _dev(coef, "coef"), P, H, W, C, _bf(dzh, "dzh"),
+    _check(lib().crw_rn_pool_bwd(_dev(d1, "d1"), _ptr(d2), _ptr(amax), _dev(Z, "Z"), _dev(coef, "coef"), P, H, W, C, _bf(dzh, "dzh"),
                                  _bf(dzl, "dzl"), _ptr(dg), _ptr(db), _ptr(ws), nbytes, _stream()), "crw_rn_pool_bwd")
     return (dzh, dzl), dg, db
 

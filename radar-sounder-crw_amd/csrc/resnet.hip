@@ -177,10 +177,11 @@ int crw_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const fl
   return launch_rn_bn_apply(Z, coef, Zd, coef_d, res_hi, res_lo, P, padded(P), npix, C, relu, y_hi, y_lo, (hipStream_t)stream);
 }
 
-int crw_rn_bn_pool(const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream) {
+int crw_rn_bn_pool(const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo, uint8_t *amax,
+                   crw_stream_t stream) {
   clear_stale_error();
   if (!Z || !coef || !y_hi || !y_lo || P < 1 || H < 1 || W < 1 || C < 8 || C % 8) return CRW_EINVAL;
-  return launch_rn_bn_pool(Z, coef, P, padded(P), H, W, C, y_hi, y_lo, (hipStream_t)stream);
+  return launch_rn_bn_pool(Z, coef, P, padded(P), H, W, C, y_hi, y_lo, amax, (hipStream_t)stream);
 }
 
 size_t crw_rn_bn_bwd_ws_bytes(int P, int npix, int C) { return (P < 1 || npix < 1 || C < 8) ? 0 : rn_bn_bwd_ws_bytes(P, npix, C); }
@@ -199,14 +200,18 @@ int crw_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, con
                           Zd ? dzd_lo : nullptr, g_out, dgamma, dbeta, dgamma_d, dbeta_d, ws, (hipStream_t)stream);
 }
 
-size_t crw_rn_pool_bwd_ws_bytes(int P, int C) { return (P < 1 || C < 64) ? 0 : rn_pool_bwd_ws_bytes(P, C); }
+size_t crw_rn_pool_bwd_ws_bytes(int P, int H, int W, int C) {
+  return (P < 1 || H < 1 || W < 1 || C < 64) ? 0 : rn_pool_bwd_ws_bytes(P, H, W, C);
+}
 
-int crw_rn_pool_bwd(const float *d1, const float *d2, const float *Z, const float *coef, int P, int H, int W, int C, uint16_t *dz_hi,
-                    uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream) {
+int crw_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int H, int W, int C,
+                    uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
-  if (!d1 || !Z || !coef || !dz_hi || !dz_lo || !dgamma || !dbeta || !ws || P < 1) return CRW_EINVAL;
-  if (ws_bytes < rn_pool_bwd_ws_bytes(P, C)) return CRW_EWORKSPACE;
-  return launch_rn_pool_bwd(d1, d2, Z, coef, P, padded(P), H, W, C, dz_hi, dz_lo, dgamma, dbeta, ws, (hipStream_t)stream);
+  if (!d1 || !amax || !Z || !coef || !dz_hi || !dz_lo || !dgamma || !dbeta || !ws || P < 1 || H < 1 || W < 1 || C < 64 || C % 64 ||
+      (C & (C - 1)) || C > 2048)
+    return CRW_EINVAL;
+  if (ws_bytes < rn_pool_bwd_ws_bytes(P, H, W, C)) return CRW_EWORKSPACE;
+  return launch_rn_pool_bwd(d1, d2, amax, Z, coef, P, padded(P), H, W, C, dz_hi, dz_lo, dgamma, dbeta, ws, (hipStream_t)stream);
 }
 
 size_t crw_rn_stem_ws_bytes(void) { return rn_stem_ws_bytes(); }

@@ -162,10 +162,11 @@ __global__ __launch_bounds__(256) void rn_bn_apply_kernel(const float *__restric
 }
 
 // relu(bn(z)) followed by the 3x3 / stride 2 / padding 1 max-pool (src/encoder.py:190-193,257-260): Z [Ppad][H*W][C] ->
-// planes [Ppad][Ho*Wo][C]
+// planes [Ppad][Ho*Wo][C]; amax (may be null) [Ppad][Ho*Wo][C] bytes: which window position ky * 3 + kx holds the maximum --
+// the FIRST one in row-major order, ATen's max_pool2d rule -- so that the backward pass routes gradients without re-deriving it
 __global__ __launch_bounds__(256) void rn_bn_pool_kernel(const float *__restrict__ Z, const float *__restrict__ coef, int P, long total_oct,
                                                          int H, int W, int Ho, int Wo, int C, uint16_t *__restrict__ y_hi,
-                                                         uint16_t *__restrict__ y_lo) {
+                                                         uint16_t *__restrict__ y_lo, uint8_t *__restrict__ amax) {
   const int c8 = C >> 3;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (long)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
@@ -173,8 +174,12 @@ __global__ __launch_bounds__(256) void rn_bn_pool_kernel(const float *__restrict
     const int o = (int)(op % (Ho * Wo));
     const long p = op / (Ho * Wo);
     Oct y;
+    int am[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) y.v[k] = 0.f;  // relu output is >= 0 and every window holds at least one pixel
+    for (int k = 0; k < 8; ++k) {
+      y.v[k] = -1.f;  // relu output is >= 0 and every window holds at least one pixel
+      am[k] = 0;
+    }
     if (p < P) {
       const Oct s = load8(coef + c), t = load8(coef + C + c);
       const int oy = o / Wo, ox = o % Wo;
@@ -186,11 +191,25 @@ __global__ __launch_bounds__(256) void rn_bn_pool_kernel(const float *__restrict
           if (ix < 0 || ix >= W) continue;
           const Oct z = load8(Z + ((p * H + iy) * W + ix) * C + c);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) y.v[k] = fmaxf(y.v[k], z.v[k] * s.v[k] + t.v[k]);
+          for (int k = 0; k < 8; ++k) {
+            const float v = fmaxf(z.v[k] * s.v[k] + t.v[k], 0.f);
+            if (v > y.v[k]) {
+              y.v[k] = v;
+              am[k] = ky * 3 + kx;
+            }
+          }
         }
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y.v[k] = 0.f;
     }
     store8_planes(y_hi + i * 8, y_lo + i * 8, y);
+    if (amax) {
+      const uint32_t lo = (uint32_t)am[0] | ((uint32_t)am[1] << 8) | ((uint32_t)am[2] << 16) | ((uint32_t)am[3] << 24);
+      const uint32_t hi = (uint32_t)am[4] | ((uint32_t)am[5] << 8) | ((uint32_t)am[6] << 16) | ((uint32_t)am[7] << 24);
+      *reinterpret_cast<uint2 *>(amax + i * 8) = uint2{lo, hi};
+    }
   }
 }
 
@@ -325,110 +344,97 @@ __global__ __launch_bounds__(256) void rn_bn_bwd_apply_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------ max-pool + bn1 backward
-// Gradient of pooled = maxpool3x3/2(relu(bn(z))) on an H x W map (9 x 9 for 16x16 patches).  Thread = (patch, channel); the
-// map of that channel lives in registers.  The arg-max of a window is its FIRST maximum in row-major order (ATen's max_pool2d).
-template <int H, int W>
-struct PoolBwd {
-  static constexpr int HO = (H - 1) / 2 + 1, WO = (W - 1) / 2 + 1;
-  // z[i] = raw convolution output of pixel i, g[i] = gradient with respect to bn(z) at pixel i (relu gate applied)
-  __device__ static inline void run(const float *__restrict__ d1, const float *__restrict__ d2, const float *__restrict__ Z, long p, int c,
-                                    int C, float scale, float shift, float (&z)[H * W], float (&g)[H * W]) {
+// Gradient of pooled = maxpool3x3/2(relu(bn(z))) with respect to bn(z) at pixel (iy, ix) of patch p, channels c..c+7: the sum
+// over the (at most four) windows that contain the pixel of their gradient where the recorded arg-max is this pixel, gated by relu.
+__device__ inline Oct pool_grad8(const float *__restrict__ d1, const float *__restrict__ d2, const uint8_t *__restrict__ amax, long p, int iy,
+                                 int ix, int c, int C, int Ho, int Wo, const Oct &z, const Oct &scale, const Oct &shift) {
+  Oct g;
 #pragma unroll
-    for (int i = 0; i < H * W; ++i) {
-      z[i] = Z[(p * (H * W) + i) * C + c];
-      g[i] = 0.f;
-    }
+  for (int k = 0; k < 8; ++k) g.v[k] = 0.f;
+  const int oy0 = iy < 1 ? 0 : iy / 2, oy1 = min(Ho - 1, (iy + 1) / 2);  // windows with 2 oy - 1 <= iy <= 2 oy + 1
+  const int ox0 = ix < 1 ? 0 : ix / 2, ox1 = min(Wo - 1, (ix + 1) / 2);
+  for (int oy = oy0; oy <= oy1; ++oy)
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const long e = ((p * Ho + oy) * Wo + ox) * C + c;
+      const int code = (iy - 2 * oy + 1) * 3 + (ix - 2 * ox + 1);
+      const uint2 a = *reinterpret_cast<const uint2 *>(amax + e);
+      Oct d = load8(d1 + e);
+      if (d2) {
+        const Oct h = load8(d2 + e);
 #pragma unroll
-    for (int oy = 0; oy < HO; ++oy)
-#pragma unroll
-      for (int ox = 0; ox < WO; ++ox) {
-        const long e = (p * (HO * WO) + oy * WO + ox) * C + c;
-        float d = d1[e];
-        if (d2) d += d2[e];
-        float best = -1.f;  // relu output >= 0
-        int am = -1;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-              const float y = fmaxf(z[iy * W + ix] * scale + shift, 0.f);
-              if (y > best) {
-                best = y;
-                am = iy * W + ix;
-              }
-            }
-          }
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) g[iy * W + ix] += (am == iy * W + ix) ? d : 0.f;
-          }
+        for (int k = 0; k < 8; ++k) d.v[k] += h.v[k];
       }
 #pragma unroll
-    for (int i = 0; i < H * W; ++i) g[i] = (z[i] * scale + shift) > 0.f ? g[i] : 0.f;
-  }
-};
-
-// block = 4 patches x 64 channels (blockIdx.y = channel block); partials [nblk][2][C]
-template <int H, int W>
-__global__ __launch_bounds__(256) void rn_pool_bwd_reduce_kernel(const float *__restrict__ d1, const float *__restrict__ d2,
-                                                                 const float *__restrict__ Z, const float *__restrict__ coef, int P, int C,
-                                                                 float *__restrict__ part) {
-  __shared__ float red[4][2][64];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  const long p = (long)blockIdx.x * 4 + pl;
-  float s0 = 0.f, s1 = 0.f;
-  if (p < P) {
-    float z[H * W], g[H * W];
-    PoolBwd<H, W>::run(d1, d2, Z, p, c, C, coef[c], coef[C + c], z, g);
-    const float mean = coef[2 * C + c], istd = coef[3 * C + c];
+      for (int k = 0; k < 8; ++k) {
+        const int am = (int)(((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xff);
+        g.v[k] += am == code ? d.v[k] : 0.f;
+      }
+    }
 #pragma unroll
-    for (int i = 0; i < H * W; ++i) {
-      s0 += g[i];
-      s1 += g[i] * ((z[i] - mean) * istd);
+  for (int k = 0; k < 8; ++k) g.v[k] = (z.v[k] * scale.v[k] + shift.v[k]) > 0.f ? g.v[k] : 0.f;
+  return g;
+}
+
+// per channel: sum g, sum g * xhat over (patches, pixels); same block shape and partial layout as rn_bn_bwd_reduce_kernel<2>
+__global__ __launch_bounds__(256) void rn_pool_bwd_reduce_kernel(const float *__restrict__ d1, const float *__restrict__ d2,
+                                                                 const uint8_t *__restrict__ amax, const float *__restrict__ Z,
+                                                                 const float *__restrict__ coef, long rows, int rows_per_block, int H, int W,
+                                                                 int C, float *__restrict__ part) {
+  extern __shared__ float red[];  // [lanes][2][C]
+  const int c8 = C >> 3, lanes = 256 / c8;
+  const int co = threadIdx.x % c8, rl = threadIdx.x / c8, c = co * 8;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[2][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[0][k] = acc[1][k] = 0.f;
+  const Oct scale = load8(coef + c), shift = load8(coef + C + c), mean = load8(coef + 2 * C + c), istd = load8(coef + 3 * C + c);
+  for (long r = r0 + rl; r < r1; r += lanes) {
+    const long p = r / (H * W);
+    const int i = (int)(r % (H * W));
+    const Oct z = load8(Z + r * C + c);
+    const Oct g = pool_grad8(d1, d2, amax, p, i / W, i % W, c, C, Ho, Wo, z, scale, shift);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[0][k] += g.v[k];
+      acc[1][k] += g.v[k] * ((z.v[k] - mean.v[k]) * istd.v[k]);
     }
   }
-  red[pl][0][cl] = s0;
-  red[pl][1][cl] = s1;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(rl * 2 + n) * C + c + k] = acc[n][k];
   __syncthreads();
-  if (pl < 2) {
-    const float s = (red[0][pl][cl] + red[1][pl][cl]) + (red[2][pl][cl] + red[3][pl][cl]);
-    part[((long)blockIdx.x * 2 + pl) * C + c] = s;
+  for (int j = threadIdx.x; j < 2 * C; j += 256) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * 2 * C + j];
+    part[(long)blockIdx.x * 2 * C + j] = s;
   }
 }
 
-template <int H, int W>
 __global__ __launch_bounds__(256) void rn_pool_bwd_apply_kernel(const float *__restrict__ d1, const float *__restrict__ d2,
-                                                                const float *__restrict__ Z, const float *__restrict__ coef,
-                                                                const float *__restrict__ kc, int P, int Ppad, int C,
-                                                                uint16_t *__restrict__ dz_hi, uint16_t *__restrict__ dz_lo) {
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  const long p = (long)blockIdx.x * 4 + pl;
-  if (p >= Ppad) return;
-  if (p >= P) {
+                                                                const uint8_t *__restrict__ amax, const float *__restrict__ Z,
+                                                                const float *__restrict__ coef, const float *__restrict__ kc, long real_oct,
+                                                                long total_oct, int H, int W, int C, uint16_t *__restrict__ dz_hi,
+                                                                uint16_t *__restrict__ dz_lo) {
+  const int c8 = C >> 3;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (long)gridDim.x * 256) {
+    Oct dz;
 #pragma unroll
-    for (int i = 0; i < H * W; ++i) {
-      dz_hi[(p * (H * W) + i) * C + c] = 0;
-      dz_lo[(p * (H * W) + i) * C + c] = 0;
+    for (int k = 0; k < 8; ++k) dz.v[k] = 0.f;
+    if (i < real_oct) {
+      const int c = (int)(i % c8) * 8;
+      const long r = i / c8;
+      const long p = r / (H * W);
+      const int px = (int)(r % (H * W));
+      const Oct z = load8(Z + i * 8), scale = load8(coef + c), shift = load8(coef + C + c), mean = load8(coef + 2 * C + c),
+                istd = load8(coef + 3 * C + c), k0 = load8(kc + c), k1 = load8(kc + C + c);
+      const Oct g = pool_grad8(d1, d2, amax, p, px / W, px % W, c, C, Ho, Wo, z, scale, shift);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz.v[k] = scale.v[k] * (g.v[k] - k0.v[k] - (z.v[k] - mean.v[k]) * istd.v[k] * k1.v[k]);
     }
-    return;
-  }
-  float z[H * W], g[H * W];
-  const float scale = coef[c];
-  PoolBwd<H, W>::run(d1, d2, Z, p, c, C, scale, coef[C + c], z, g);
-  const float mean = coef[2 * C + c], istd = coef[3 * C + c], k0 = kc[c], k1 = kc[C + c];
-#pragma unroll
-  for (int i = 0; i < H * W; ++i) {
-    const float dz = scale * (g[i] - k0 - (z[i] - mean) * istd * k1);
-    const uint16_t h = f2bf(dz);
-    dz_hi[(p * (H * W) + i) * C + c] = h;
-    dz_lo[(p * (H * W) + i) * C + c] = f2bf(dz - bf2f(h));
+    store8_planes(dz_hi + i * 8, dz_lo + i * 8, dz);
   }
 }
 
@@ -713,10 +719,10 @@ int launch_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const
 }
 
 int launch_rn_bn_pool(const float *Z, const float *coef, int P, int Ppad, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo,
-                      hipStream_t s) {
+                      uint8_t *amax, hipStream_t s) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long total = (long)Ppad * Ho * Wo * C / 8;
-  hipLaunchKernelGGL(rn_bn_pool_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, coef, P, total, H, W, Ho, Wo, C, y_hi, y_lo);
+  hipLaunchKernelGGL(rn_bn_pool_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, coef, P, total, H, W, Ho, Wo, C, y_hi, y_lo, amax);
   return check_launch();
 }
 
@@ -758,24 +764,26 @@ int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, 
   return check_launch();
 }
 
-size_t rn_pool_bwd_ws_bytes(int P, int C) {
-  const long nblk = (P + 3) / 4;
-  return align_up((size_t)nblk * 2 * C * 4, 256) + (size_t)64 * 2 * C * 8 + (size_t)2 * C * 4 + 256;
-}
+size_t rn_pool_bwd_ws_bytes(int P, int H, int W, int C) { return rn_bn_bwd_ws_bytes(P, H * W, C); }
 
-int launch_rn_pool_bwd(const float *d1, const float *d2, const float *Z, const float *coef, int P, int Ppad, int H, int W, int C,
-                       uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
-  if (H != 9 || W != 9 || C % 64) return CRW_EINVAL;  // 16x16 patches
-  const int nblk = (P + 3) / 4;
+int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int Ppad, int H,
+                       int W, int C, uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
+  if (C % 8 || C / 8 > 256 || 256 % (C / 8)) return CRW_EINVAL;
+  const long rows = (long)P * H * W;
+  int rpb = (int)((rows + 2047) / 2048);
+  if (rpb < 256) rpb = 256;
+  const int nblk = (int)((rows + rpb - 1) / rpb);
   float *part = (float *)ws;
-  double *part2 = (double *)((char *)ws + align_up((size_t)nblk * 2 * C * 4, 256));
-  float *kc = (float *)(part2 + (size_t)64 * 2 * C);
-  hipLaunchKernelGGL((rn_pool_bwd_reduce_kernel<9, 9>), dim3(nblk, C / 64), dim3(256), 0, s, d1, d2, Z, coef, P, C, part);
+  double *part2 = (double *)((char *)ws + align_up((size_t)((rows + 255) / 256 + 1) * 3 * C * 4, 256));
+  float *kc = (float *)(part2 + (size_t)64 * 3 * C);
+  hipLaunchKernelGGL(rn_pool_bwd_reduce_kernel, dim3(nblk), dim3(256), (size_t)256 * 8 * 2 * 4, s, d1, d2, amax, Z, coef, rows, rpb, H, W, C,
+                     part);
   const int R2 = rn_rows_reduce(part, nblk, 2 * C, part2, s);
-  hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<2>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)P * H * W, dgamma, dbeta,
+  hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<2>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
                      (float *)nullptr, (float *)nullptr, kc);
-  hipLaunchKernelGGL((rn_pool_bwd_apply_kernel<9, 9>), dim3((Ppad + 3) / 4, C / 64), dim3(256), 0, s, d1, d2, Z, coef, kc, P, Ppad, C,
-                     dz_hi, dz_lo);
+  const long real = rows * C / 8, total = (long)Ppad * H * W * C / 8;
+  hipLaunchKernelGGL(rn_pool_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, d1, d2, amax, Z, coef, kc, real, total, H, W, C, dz_hi,
+                     dz_lo);
   return check_launch();
 }
 

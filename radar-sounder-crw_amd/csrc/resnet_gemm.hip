@@ -496,12 +496,13 @@ int rn_conv_bk() {
 int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
   if (a.N % 64 || a.mtiles < 1 || a.G < 1 || a.KH * a.KW > RN_MAXSEG) return CRW_EINVAL;
   const bool wide = a.N % 128 == 0;
-  // measured in the training step (r03): the 64-column tiles (layer1, the stem forward) are 20 % faster on three 32-deep
-  // stages (72 KB of LDS: two workgroups per CU cover each other's short k-loops); the 128-column tiles and the long single
-  // segment of the stem's backward-data product prefer two 64-deep stages
+  // measured in the training step (r03): the k-loops are short (4-18 tiles), so what pays is a second workgroup on the CU that
+  // covers the first one's prologue / epilogue: 32-deep k-tiles -- three stages for the 64-column tiles (72 KB of LDS; layer1 and
+  // the stem forward 20 % faster than on two 64-deep stages), two stages for the 128-column tiles (64 KB; step 6.9 -> 6.6 ms);
+  // the long single segment of the stem's backward-data product prefers two 64-deep stages.  CRW_RN_BK = 64 | 32 | 322 forces one.
   int bk = rn_conv_bk();
-  if (bk != 32 && bk != 64 && bk != 322) bk = (wide || a.mode == RN_MODE_STEM_BWD) ? 64 : 32;
-  if (bk == 322) return wide ? launch_conv_cfg<128, 32, 2>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);  // A/B: wide tiles, two per CU
+  if (bk != 32 && bk != 64 && bk != 322) bk = a.mode == RN_MODE_STEM_BWD ? 64 : 322;
+  if (bk == 322) return wide ? launch_conv_cfg<128, 32, 2>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);
   if (bk == 32) return wide ? launch_conv_cfg<128, 32, 3>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);
   return wide ? launch_conv_cfg<128, 64, 2>(a, s) : launch_conv_cfg<64, 64, 2>(a, s);
 }
@@ -522,8 +523,10 @@ int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s) {
   const bool m128 = a.Mtot % 128 == 0, n128 = a.Ntot % 128 == 0;
   static int bk = -1;
   if (bk < 0) {
-    const char *e = getenv("CRW_RN_WBK");  // A/B knob: patches per k-tile of the weight gradient (64: one workgroup per CU at 128 x 128)
-    bk = e ? atoi(e) : 0;
+    // patches per k-tile of the weight gradient: 32 (two 32 KB stages at 128 x 128: two workgroups per CU; step 6.9 -> 6.6 ms
+    // against 64-patch tiles with one workgroup per CU); CRW_RN_WBK=64 restores the deeper tiles for A/B runs
+    const char *e = getenv("CRW_RN_WBK");
+    bk = e ? atoi(e) : 32;
   }
   int st;
   if (bk == 32) {

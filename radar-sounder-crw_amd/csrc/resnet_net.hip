@@ -10,7 +10,7 @@ using namespace crw;
 
 namespace {
 
-constexpr int NPARAM = 42, NBN = 13, FEAT = 128;
+constexpr int NPARAM = CRW_RN_NPARAM, FEAT = 128;
 
 struct Blk {
   int cin, cout, stride, hin, win, hout, wout, down;
@@ -48,6 +48,7 @@ struct Plan {
   uint16_t *wsf_h, *wsf_l, *wst_h, *wst_l;
   Planes xmap, A1;
   float *Z1, *coef1;
+  uint8_t *amax1;  // arg-max codes of the max-pool
   struct {
     Wpack wa, wb, wd;
     float *Za, *Zb, *Zd, *ca, *cb, *cd;
@@ -83,8 +84,9 @@ struct Plan {
       b.pbase = pbase[i]; b.bn = bnidx[i];
       hh = b.hout; ww = b.wout; c = b.cout;
     }
-    // the kernels of this build cover the 16 x 16 patches of the reference's defaults: 9 x 9 map after the stem, 1 x 1 at the head
-    if (hh != 1 || ww != 1 || H1 != 9 || W1 != 9 || 3 * W0 > 64 || cin < 1 || cin > 2) ok = false;
+    // covered: patch sizes whose map is 1 x 1 at the head (the average pool is then the identity) and at most 21 columns wide
+    // (one 64-column tile per map row in the stem's backward-data product); 16 x 16, the reference's default, is the tested one
+    if (hh != 1 || ww != 1 || 3 * W0 > 64 || cin < 1 || cin > 2) ok = false;
     if (!ok) return;
     const size_t pp = (size_t)Ppad;
     stem = take<float>(32);
@@ -94,6 +96,7 @@ struct Plan {
     Z1 = take<float>(pp * H1 * W1 * 64);
     coef1 = take<float>(4 * 64);
     A1 = planes(pp * H2 * W2 * 64);
+    amax1 = take<uint8_t>(pp * H2 * W2 * 64);
     size_t gmax = pp * H2 * W2 * 64, part_max = crw_rn_conv_part_floats(P, H1 * W1, 64);
     for (int i = 0; i < 4; ++i) {
       const Blk &b = blk[i];
@@ -136,7 +139,7 @@ struct Plan {
     }
     wgrad_ws = take<char>(wgrad_bytes);
     bnbwd_ws = take<char>(bnb);
-    poolbwd_ws = take<char>(rn_pool_bwd_ws_bytes(P, 64));
+    poolbwd_ws = take<char>(rn_pool_bwd_ws_bytes(P, H1, W1, 64));
     colsum_ws = take<char>(rn_colsum_ws_bytes(FEAT));
     off = align_up(off, 256);
   }
@@ -222,7 +225,7 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
   CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1, pl.part));
   CRW_TRY(launch_rn_bn_stats(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1),
                              momentum, eps, pl.coef1, pl.stats_ws, s));
-  CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, s));
+  CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, pl.amax1, s));
 
   Planes A = pl.A1;
   for (int i = 0; i < 4; ++i) {
@@ -301,7 +304,7 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
     flip ^= 1;
   }
   // max-pool + bn1, stem convolution, stem
-  CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
+  CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.amax1, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
   CRW_TRY(wgrad(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.dz1, grads[4], pl.wgrad_ws));
   CRW_TRY(conv(s, RN_MODE_STEM_BWD, P, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3, pl.dz1, pl.wst_h, pl.wst_l, nullptr, pl.dX0, nullptr));
   CRW_TRY(launch_rn_stem_bwd(pl.dX0, x, pl.stem, prm[0], prm[1], P, cin, h, w, 64, grads[0], grads[1], grads[2], grads[3], pl.stem_ws, s));

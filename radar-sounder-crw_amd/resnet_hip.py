@@ -84,7 +84,7 @@ class HipResnetFn(torch.autograd.Function):
             b = _Block(getattr(body, f"layer{i}")[0], hh, ww)
             blocks.append(b)
             hh, ww = b.hout, b.wout
-        if (hh, ww) != (1, 1) or (H1, W1) != (9, 9):
+        if (hh, ww) != (1, 1):
             raise RuntimeError(f"HIP Resnet path: unsupported patch size {h}x{w}")
         sv = {"geo": (P, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm), "x": x, "blocks": blocks}
 
@@ -93,8 +93,8 @@ class HipResnetFn(torch.autograd.Function):
         xmap, stem = H.rn_stem_fwd(x, net.fc0, net.bn0, Hm, Wm, mom)
         Z1, part = H.rn_conv(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1), 64, (7, 7), 2, 3, xmap, wstem[:2], stats=True)
         coef1 = H.rn_bn_stats(part, P, H1 * W1, body.bn1, mom)
-        A = H.rn_bn_pool(Z1, coef1, P, H1, W1, 64)
-        sv.update(wstem=wstem, xmap=xmap, stem=stem, Z1=Z1, coef1=coef1)
+        A, amax = H.rn_bn_pool(Z1, coef1, P, H1, W1, 64)
+        sv.update(wstem=wstem, xmap=xmap, stem=stem, Z1=Z1, coef1=coef1, amax=amax)
 
         # ---- residual stages
         recs = []
@@ -173,7 +173,7 @@ class HipResnetFn(torch.autograd.Function):
             else:
                 g2 = gres
         # max-pool + bn1, stem convolution, stem
-        dz1, dg, db = H.rn_pool_bwd(g1, g2, sv["Z1"], sv["coef1"], P, H1, W1, 64)
+        dz1, dg, db = H.rn_pool_bwd(g1, g2, sv["amax"], sv["Z1"], sv["coef1"], P, H1, W1, 64)
         grads["model.bn1.weight"], grads["model.bn1.bias"] = dg, db
         grads["model.conv1.weight"] = H.rn_wgrad(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1, 64), (7, 7), 2, 3, sv["xmap"], dz1)
         dX0, _ = H.rn_conv(H.RN_STEM_BWD, P, (H1, W1, 64), (H0, 1), 64, (7, 7), 2, 3, dz1, sv["wstem"][2:])

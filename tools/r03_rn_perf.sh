@@ -7,7 +7,7 @@ run() { timeout -k 10 300 env "$@" python bench.py --model 1 --no-probe --no-cpu
 import sys,json; d=json.loads(sys.stdin.read()); print('$*', 'ms/step %.3f' % d['ms_per_step'], 'loss', d['config']['loss'])
 for k in d.get('roofline_kernels', [])[:40]: print('   %-72s x%d %7.1f us  alg %.3f exec %.3f' % (k['kernel'][:72], k['launches_per_step'], k['launch_us'], k['frac'], k['mfma_executed_frac']))
 "; }
-run CRW_RN_BK=64
+run CRW_DEFAULT=1
 for kv in "$@"; do run $kv; done
 if [ -z "$NOPROF" ]; then
 cd /tmp && export TMPDIR=/tmp
