@@ -266,6 +266,9 @@ int crw_rn_wgrad(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout,
 size_t crw_rn_bn_stats_ws_bytes(int C);
 int crw_rn_bn_stats(const float *part, int P, int G, int C, const float *gamma, const float *beta, float *run_mean, float *run_var,
                     float momentum, float eps, float *coef, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* the same from `rows` partial rows [rows][C] of (sum, sum of squares) over `count` samples per channel (crw_rn_stem16_fwd's) */
+int crw_rn_bn_stats_rows(const float *part, int rows, double count, int C, const float *gamma, const float *beta, float *run_mean,
+                         float *run_var, float momentum, float eps, float *coef, void *ws, size_t ws_bytes, crw_stream_t stream);
 /* y planes = relu?( Z * scale + shift [+ Zd * scale_d + shift_d] [+ residual planes] )   (src/encoder.py:138-153) */
 int crw_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
                     const uint16_t *res_lo, int P, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream);
@@ -297,6 +300,27 @@ int crw_rn_stem_fwd(const float *x, int P, int cin, int h, int w, int Hm, int Wm
 /* dX0 = out of crw_rn_conv mode 3 -> dw0 [3][cin], db0 [3], dgamma0 [3], dbeta0 [3] */
 int crw_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
                     float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream);
+/* The stem for 16 x 16 patches, one PATCH per wave (what crw_rn_train_* use at that size; csrc/resnet_stem.hip): the map
+ * relu0(bn0(fc0(x))) is rebuilt from the 1 KB patch inside each kernel (LDS image), the 7 x 7 weights live in LDS in MFMA fragment
+ * order, and the backward-data pass never writes the gradient map -- only the sums bn0 / fc0 need leave it.
+ *   crw_rn_stem_stats   : bn0's batch statistics (from the moments of x) -> stem[32] record (+ running statistics)
+ *   crw_rn_pack_stem16  : model.conv1.weight [64][3][7][7] -> forward / transposed fragment packs (28672 bf16 each)
+ *   crw_rn_stem16_fwd   : Z1 [P][81][64] fp32 + crw_rn_stem16_rows() partial rows [64] of (sum, sum of squares) for crw_rn_bn_stats_rows
+ *   crw_rn_stem16_wgrad : dz planes [P][81][64] (gradient of Z1) -> dw1 [64][3][7][7]
+ *   crw_rn_stem16_bwd   : dz planes -> dw0 [3][cin], db0 [3], dgamma0 [3], dbeta0 [3]
+ * ws of the last two: crw_rn_stem16_ws_bytes(); of crw_rn_stem_stats: crw_rn_stem_ws_bytes(). */
+int crw_rn_stem_stats(const float *x, int P, int cin, int h, int w, const float *w0, const float *b0, const float *gamma, const float *beta,
+                      float *run_mean, float *run_var, float momentum, float eps, float *stem, void *ws, size_t ws_bytes,
+                      crw_stream_t stream);
+int crw_rn_stem16_rows(void);
+int crw_rn_pack_stem16(const float *w1, uint16_t *wf, uint16_t *wt, crw_stream_t stream);
+int crw_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, const uint16_t *wf, float *Z1, float *part, crw_stream_t stream);
+size_t crw_rn_stem16_ws_bytes(void);
+int crw_rn_stem16_wgrad(const float *x, int P, int cin, const float *stem, const uint16_t *dz_hi, const uint16_t *dz_lo, float *dw, void *ws,
+                        size_t ws_bytes, crw_stream_t stream);
+int crw_rn_stem16_bwd(const float *x, int P, int cin, const float *stem, const float *w0, const float *b0, const uint16_t *wt,
+                      const uint16_t *dz_hi, const uint16_t *dz_lo, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws,
+                      size_t ws_bytes, crw_stream_t stream);
 /* fp32 [P][C] -> planes [Ppad][C] */
 int crw_rn_split(const float *x, int P, int C, uint16_t *hi, uint16_t *lo, crw_stream_t stream);
 /* out [C] = column sums of x [rows][C] (bias gradient of the head), fixed order */

@@ -95,6 +95,14 @@ SIGNATURES = {
     "crw_rn_split": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "crw_rn_colsum_ws_bytes": (_c_sz, [_c_int]),
     "crw_rn_colsum": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_sz, _p]),
+    "crw_rn_bn_stats_rows": (_c_int, [_p, _c_int, ctypes.c_double, _c_int, _p, _p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
+    "crw_rn_stem_stats": (_c_int, [_p] + [_c_int] * 4 + [_p] * 6 + [_c_f, _c_f, _p, _p, _c_sz, _p]),
+    "crw_rn_stem16_rows": (_c_int, []),
+    "crw_rn_pack_stem16": (_c_int, [_p, _p, _p, _p]),
+    "crw_rn_stem16_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "crw_rn_stem16_ws_bytes": (_c_sz, []),
+    "crw_rn_stem16_wgrad": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _c_sz, _p]),
+    "crw_rn_stem16_bwd": (_c_int, [_p, _c_int, _c_int] + [_p] * 11 + [_c_sz, _p]),
     "crw_rn_train_ws_bytes": (_c_sz, [_c_int] * 4),
     "crw_rn_train_fwd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
     "crw_rn_train_bwd": (_c_int, [_p, _p] + [_c_int] * 4 + [_p, _p, _p, _c_sz, _p]),
@@ -685,6 +693,70 @@ def rn_stem_bwd(dX0, x, stem, w0, b0):
     _check(lib().crw_rn_stem_bwd(_dev(dX0, "dX0"), _dev(x, "x"), _dev(stem, "stem"), _dev(w0.reshape(3, cin).contiguous(), "w0"),
                                  _dev(b0, "b0"), P, cin, h, w, _dev(dw0, "dw0"), _dev(db0, "db0"), _dev(dg, "dg"), _dev(db, "db"),
                                  _ptr(ws), nbytes, _stream()), "crw_rn_stem_bwd")
+    return dw0, db0, dg, db
+
+
+def rn_stem_stats(x, fc0, bn0, momentum):
+    """bn0's batch statistics from the moments of the patches -> stem record [32] (updates bn0's running statistics)"""
+    P, cin, h, w = x.shape
+    stem = torch.empty(32, dtype=torch.float32, device=x.device)
+    nbytes = lib().crw_rn_stem_ws_bytes()
+    ws = _ws(nbytes, x.device)
+    _check(lib().crw_rn_stem_stats(_dev(x, "x"), P, cin, h, w, _dev(fc0.weight.detach().reshape(3, cin).contiguous(), "w0"),
+                                   _dev(fc0.bias.detach(), "b0"), _dev(bn0.weight.detach(), "gamma"), _dev(bn0.bias.detach(), "beta"),
+                                   _ptr(bn0.running_mean), _ptr(bn0.running_var), float(momentum), float(bn0.eps), _dev(stem, "stem"),
+                                   _ptr(ws), nbytes, _stream()), "crw_rn_stem_stats")
+    return stem
+
+
+def rn_pack_stem16(w1):
+    wf = torch.empty(28672, dtype=_BF, device=w1.device)
+    wt = torch.empty_like(wf)
+    _check(lib().crw_rn_pack_stem16(_dev(w1.detach().contiguous(), "w1"), _bf(wf, "wf"), _bf(wt, "wt"), _stream()), "crw_rn_pack_stem16")
+    return wf, wt
+
+
+def rn_stem16_fwd(x, stem, wf):
+    """-> (Z1 [Ppad, 81*64] fp32 (rows of the padding patches zero), part [rows, 64, 2])"""
+    P, cin = x.shape[:2]
+    Z1 = torch.zeros(rn_padded(P), 81 * 64, dtype=torch.float32, device=x.device)
+    part = torch.empty(lib().crw_rn_stem16_rows(), 64, 2, dtype=torch.float32, device=x.device)
+    _check(lib().crw_rn_stem16_fwd(_dev(x, "x"), P, cin, _dev(stem, "stem"), _bf(wf, "wf"), _dev(Z1, "Z1"), _dev(part, "part"),
+                                   _stream()), "crw_rn_stem16_fwd")
+    return Z1, part
+
+
+def rn_bn_stats_rows(part, count, bn, momentum):
+    rows, C = part.shape[0], bn.weight.numel()
+    coef = torch.empty(4, C, dtype=torch.float32, device=part.device)
+    nbytes = lib().crw_rn_bn_stats_ws_bytes(C)
+    ws = _ws(nbytes, part.device)
+    _check(lib().crw_rn_bn_stats_rows(_dev(part, "part"), rows, float(count), C, _dev(bn.weight.detach(), "gamma"),
+                                      _dev(bn.bias.detach(), "beta"), _ptr(bn.running_mean), _ptr(bn.running_var), float(momentum),
+                                      float(bn.eps), _dev(coef, "coef"), _ptr(ws), nbytes, _stream()), "crw_rn_bn_stats_rows")
+    return coef
+
+
+def rn_stem16_wgrad(x, stem, dz):
+    P, cin = x.shape[:2]
+    dw = torch.empty(64, 3, 7, 7, dtype=torch.float32, device=x.device)
+    nbytes = lib().crw_rn_stem16_ws_bytes()
+    ws = _ws(nbytes, x.device)
+    _check(lib().crw_rn_stem16_wgrad(_dev(x, "x"), P, cin, _dev(stem, "stem"), _bf(dz[0], "dz_hi"), _bf(dz[1], "dz_lo"), _dev(dw, "dw"),
+                                     _ptr(ws), nbytes, _stream()), "crw_rn_stem16_wgrad")
+    return dw
+
+
+def rn_stem16_bwd(x, stem, w0, b0, wt, dz):
+    P, cin = x.shape[:2]
+    dev = x.device
+    dw0 = torch.empty(3, cin, 1, 1, dtype=torch.float32, device=dev)
+    db0, dg, db = (torch.empty(3, dtype=torch.float32, device=dev) for _ in range(3))
+    nbytes = lib().crw_rn_stem16_ws_bytes()
+    ws = _ws(nbytes, dev)
+    _check(lib().crw_rn_stem16_bwd(_dev(x, "x"), P, cin, _dev(stem, "stem"), _dev(w0.reshape(3, cin).contiguous(), "w0"), _dev(b0, "b0"),
+                                   _bf(wt, "wt"), _bf(dz[0], "dz_hi"), _bf(dz[1], "dz_lo"), _dev(dw0, "dw0"), _dev(db0, "db0"),
+                                   _dev(dg, "dg"), _dev(db, "db"), _ptr(ws), nbytes, _stream()), "crw_rn_stem16_bwd")
     return dw0, db0, dg, db
 
 

@@ -66,6 +66,11 @@ size_t rn_stem_ws_bytes();
 int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
                        const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,
                        uint16_t *m_hi, uint16_t *m_lo, float *stem, void *ws, hipStream_t s);
+int launch_rn_stem_stats(const float *x, int P, int cin, int h, int w, const float *w0, const float *b0, const float *gamma,
+                         const float *beta, float *run_mean, float *run_var, float momentum, float eps, float *stem, void *ws,
+                         hipStream_t s);
+int launch_rn_stem_bwd_finalize(const float *part, int rows, int cin, const float *stem, const float *w0, const float *b0, float *dw0,
+                                float *db0, float *dgamma, float *dbeta, void *ws /* 64 * 16 doubles */, hipStream_t s);
 int launch_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
                        int ldx, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, hipStream_t s);
 int launch_rn_pack_conv(const float *w, int cout, int cin, int T, uint16_t *fh, uint16_t *fl, uint16_t *bh, uint16_t *bl, hipStream_t s);
@@ -74,5 +79,17 @@ int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt
 int launch_rn_split(const float *x, long rows, long rows_pad, int C, uint16_t *hi, uint16_t *lo, hipStream_t s);
 size_t rn_colsum_ws_bytes(int W);
 int launch_rn_colsum(const float *x, int R, int W, float *out, void *ws, hipStream_t s);
+
+// resnet_stem.hip: the stem convolution for 16 x 16 patches, a patch per wave -----------------------------------------------
+constexpr int RN_STEM_FRAG_ELEMS = 7 * 4 * 2 * 512;  // bf16 elements of one fragment-ordered weight pack (hi and lo interleaved per fragment)
+int rn_stem16_blocks();
+int launch_rn_pack_stem_frag(const float *w1, uint16_t *wf, uint16_t *wt, hipStream_t s);
+int launch_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, const uint16_t *wf, float *Z1, float *part /* [blocks*8][64][2] */,
+                         hipStream_t s);
+int launch_rn_stem16_wgrad(const float *x, int P, int cin, const float *stem, const uint16_t *dz_hi, const uint16_t *dz_lo,
+                           float *slab /* [blocks*4][224][64] */, hipStream_t s);
+int launch_rn_stem16_bwd(const float *x, int P, int cin, const float *stem, const float *w0, const float *b0, const uint16_t *wt,
+                         const uint16_t *dz_hi, const uint16_t *dz_lo, float *part /* [blocks*8][16] */, hipStream_t s);
+int launch_rn_stem_slab_reduce(const float *slab, int nslab, float *dw, hipStream_t s);
 
 }  // namespace crw

@@ -168,6 +168,15 @@ int crw_rn_bn_stats(const float *part, int P, int G, int C, const float *gamma, 
                             (double *)ws, (hipStream_t)stream);
 }
 
+int crw_rn_bn_stats_rows(const float *part, int rows, double count, int C, const float *gamma, const float *beta, float *run_mean,
+                         float *run_var, float momentum, float eps, float *coef, void *ws, size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!part || !gamma || !beta || !coef || !ws || rows < 1 || count < 1.0 || C < 1 || (run_mean == nullptr) != (run_var == nullptr))
+    return CRW_EINVAL;
+  if (ws_bytes < crw_rn_bn_stats_ws_bytes(C)) return CRW_EWORKSPACE;
+  return launch_rn_bn_stats(part, rows, C, count, gamma, beta, run_mean, run_var, momentum, eps, coef, (double *)ws, (hipStream_t)stream);
+}
+
 int crw_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
                     const uint16_t *res_lo, int P, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, crw_stream_t stream) {
   clear_stale_error();
@@ -236,6 +245,58 @@ int crw_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const f
     return CRW_EINVAL;
   if (ws_bytes < rn_stem_ws_bytes()) return CRW_EWORKSPACE;
   return launch_rn_stem_bwd(dX0, x, stem, w0, b0, P, cin, h, w, 64, dw0, db0, dgamma, dbeta, ws, (hipStream_t)stream);
+}
+
+/* ---- stem convolution for 16 x 16 patches, a patch per wave (resnet_stem.hip) ---- */
+int crw_rn_stem_stats(const float *x, int P, int cin, int h, int w, const float *w0, const float *b0, const float *gamma, const float *beta,
+                      float *run_mean, float *run_var, float momentum, float eps, float *stem, void *ws, size_t ws_bytes,
+                      crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !w0 || !b0 || !gamma || !beta || !stem || !ws || P < 1 || cin < 1 || cin > 2 || h < 1 || w < 1 ||
+      (run_mean == nullptr) != (run_var == nullptr))
+    return CRW_EINVAL;
+  if (ws_bytes < rn_stem_ws_bytes()) return CRW_EWORKSPACE;
+  return launch_rn_stem_stats(x, P, cin, h, w, w0, b0, gamma, beta, run_mean, run_var, momentum, eps, stem, ws, (hipStream_t)stream);
+}
+
+int crw_rn_stem16_rows(void) { return rn_stem16_blocks() * 8; }
+
+int crw_rn_pack_stem16(const float *w1, uint16_t *wf, uint16_t *wt, crw_stream_t stream) {
+  clear_stale_error();
+  if (!w1 || !wf || !wt) return CRW_EINVAL;
+  return launch_rn_pack_stem_frag(w1, wf, wt, (hipStream_t)stream);
+}
+
+int crw_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, const uint16_t *wf, float *Z1, float *part, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !stem || !wf || !Z1 || !part || P < 1 || cin < 1 || cin > 2) return CRW_EINVAL;
+  return launch_rn_stem16_fwd(x, P, cin, stem, wf, Z1, part, (hipStream_t)stream);
+}
+
+size_t crw_rn_stem16_ws_bytes(void) {
+  return align_up((size_t)rn_stem16_blocks() * 4 * 224 * 64 * 4, 256) + (size_t)rn_stem16_blocks() * 8 * 16 * 4 + 64 * 16 * 8 + 256;
+}
+
+int crw_rn_stem16_wgrad(const float *x, int P, int cin, const float *stem, const uint16_t *dz_hi, const uint16_t *dz_lo, float *dw, void *ws,
+                        size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !stem || !dz_hi || !dz_lo || !dw || !ws || P < 1 || cin < 1 || cin > 2) return CRW_EINVAL;
+  if (ws_bytes < crw_rn_stem16_ws_bytes()) return CRW_EWORKSPACE;
+  CRW_TRY(launch_rn_stem16_wgrad(x, P, cin, stem, dz_hi, dz_lo, (float *)ws, (hipStream_t)stream));
+  return launch_rn_stem_slab_reduce((const float *)ws, rn_stem16_blocks() * 4, dw, (hipStream_t)stream);
+}
+
+int crw_rn_stem16_bwd(const float *x, int P, int cin, const float *stem, const float *w0, const float *b0, const uint16_t *wt,
+                      const uint16_t *dz_hi, const uint16_t *dz_lo, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws,
+                      size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !stem || !w0 || !b0 || !wt || !dz_hi || !dz_lo || !dw0 || !db0 || !dgamma || !dbeta || !ws || P < 1 || cin < 1 || cin > 2)
+    return CRW_EINVAL;
+  if (ws_bytes < crw_rn_stem16_ws_bytes()) return CRW_EWORKSPACE;
+  float *part = (float *)ws;
+  void *ws2 = (char *)ws + align_up((size_t)rn_stem16_blocks() * 8 * 16 * 4, 256);
+  CRW_TRY(launch_rn_stem16_bwd(x, P, cin, stem, w0, b0, wt, dz_hi, dz_lo, part, (hipStream_t)stream));
+  return launch_rn_stem_bwd_finalize(part, rn_stem16_blocks() * 8, cin, stem, w0, b0, dw0, db0, dgamma, dbeta, ws2, (hipStream_t)stream);
 }
 
 int crw_rn_split(const float *x, int P, int C, uint16_t *hi, uint16_t *lo, crw_stream_t stream) {

@@ -790,15 +790,23 @@ int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, co
 constexpr int STEM_BLOCKS = 1024;
 size_t rn_stem_ws_bytes() { return (size_t)STEM_BLOCKS * 16 * 4 + (size_t)64 * 16 * 8 + 256; }
 
-int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
-                       const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,
-                       uint16_t *m_hi, uint16_t *m_lo, float *stem, void *ws, hipStream_t s) {
+// bn0's batch statistics from the moments of the patches -> the stem record (no map is written)
+int launch_rn_stem_stats(const float *x, int P, int cin, int h, int w, const float *w0, const float *b0, const float *gamma,
+                         const float *beta, float *run_mean, float *run_var, float momentum, float eps, float *stem, void *ws,
+                         hipStream_t s) {
   float *part = (float *)ws;
   double *part2 = (double *)((char *)ws + (size_t)STEM_BLOCKS * 16 * 4);
   hipLaunchKernelGGL(rn_stem_moments_kernel, dim3(STEM_BLOCKS), dim3(256), 0, s, x, P, cin, h * w, part);
   const int R2 = rn_rows_reduce(part, STEM_BLOCKS, 8, part2, s);
   hipLaunchKernelGGL(rn_stem_finalize_kernel, dim3(1), dim3(64), 0, s, part2, R2, cin, (double)P * (h + 2) * (w + 2), w0, b0, gamma, beta,
                      run_mean, run_var, momentum, eps, stem);
+  return check_launch();
+}
+
+int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
+                       const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,
+                       uint16_t *m_hi, uint16_t *m_lo, float *stem, void *ws, hipStream_t s) {
+  CRW_TRY(launch_rn_stem_stats(x, P, cin, h, w, w0, b0, gamma, beta, run_mean, run_var, momentum, eps, stem, ws, s));
   const long total_px = (long)Ppad * Hm * Wm;
   hipLaunchKernelGGL(rn_stem_apply_kernel, dim3(grid_for(total_px)), dim3(256), 0, s, x, stem, P, total_px, cin, h, w, Hm, Wm, m_hi, m_lo);
   return check_launch();
@@ -810,6 +818,15 @@ int launch_rn_stem_bwd(const float *dX0, const float *x, const float *stem, cons
   double *part2 = (double *)((char *)ws + (size_t)STEM_BLOCKS * 16 * 4);
   hipLaunchKernelGGL(rn_stem_bwd_reduce_kernel, dim3(STEM_BLOCKS), dim3(256), 0, s, dX0, x, stem, w0, b0, P, cin, h, w, ldx, part);
   const int R2 = rn_rows_reduce(part, STEM_BLOCKS, 16, part2, s);
+  hipLaunchKernelGGL(rn_stem_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, part2, R2, cin, stem, w0, b0, dw0, db0, dgamma, dbeta);
+  return check_launch();
+}
+
+// the stem's backward sums as per-wave partials part [rows][16] (rn_stem_bwd_kernel) -> dw0, db0, dgamma0, dbeta0
+int launch_rn_stem_bwd_finalize(const float *part, int rows, int cin, const float *stem, const float *w0, const float *b0, float *dw0,
+                                float *db0, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
+  double *part2 = (double *)ws;
+  const int R2 = rn_rows_reduce(part, rows, 16, part2, s);
   hipLaunchKernelGGL(rn_stem_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, part2, R2, cin, stem, w0, b0, dw0, db0, dgamma, dbeta);
   return check_launch();
 }

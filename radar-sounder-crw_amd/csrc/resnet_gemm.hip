@@ -507,6 +507,16 @@ int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
   return wide ? launch_conv_cfg<128, 64, 2>(a, s) : launch_conv_cfg<64, 64, 2>(a, s);
 }
 
+// dw [64][3][7][7] = sum of `nslab` slabs [224][64] (rn_stem_wgrad_kernel: one per wave pair), fixed order
+int launch_rn_stem_slab_reduce(const float *slab, int nslab, float *dw, hipStream_t s) {
+  RnWgradArgs a{};
+  a.slab = const_cast<float *>(slab);
+  a.S = nslab; a.taps = 1; a.ntv = 1; a.Mtot = 224; a.Ntot = 64;
+  a.tapv[0] = 0; a.tapinv[0] = 0;
+  hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((224 * 64 + 63) / 64), dim3(256), 0, s, a, 1, dw);
+  return check_launch();
+}
+
 int rn_wgrad_slices(const RnWgradArgs &a) {
   const int tm = a.Mtot % 128 ? 64 : 128, tn = a.Ntot % 128 ? 64 : 128;
   const int tiles = a.ntv * (a.Mtot / tm) * (a.Ntot / tn);

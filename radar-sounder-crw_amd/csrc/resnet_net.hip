@@ -46,6 +46,9 @@ struct Plan {
   // forward (kept for the backward)
   float *stem;
   uint16_t *wsf_h, *wsf_l, *wst_h, *wst_l;
+  bool stem16;           // 16 x 16 patches: the patch-per-wave stem kernels (resnet_stem.hip), no map / Toeplitz planes in HBM
+  uint16_t *w16f, *w16t;  // their weight fragment packs
+  float *stem_part;
   Planes xmap, A1;
   float *Z1, *coef1;
   uint8_t *amax1;  // arg-max codes of the max-pool
@@ -90,14 +93,21 @@ struct Plan {
     if (!ok) return;
     const size_t pp = (size_t)Ppad;
     stem = take<float>(32);
-    wsf_h = take<uint16_t>(64 * 256); wsf_l = take<uint16_t>(64 * 256);
-    wst_h = take<uint16_t>((size_t)H0 * 64 * ldt); wst_l = take<uint16_t>((size_t)H0 * 64 * ldt);
-    xmap = planes(pp * Hm * Wm * 4);
+    stem16 = (h == 16 && w == 16);
+    if (stem16) {
+      w16f = take<uint16_t>(RN_STEM_FRAG_ELEMS);
+      w16t = take<uint16_t>(RN_STEM_FRAG_ELEMS);
+      stem_part = take<float>((size_t)rn_stem16_blocks() * 8 * 16);
+    } else {
+      wsf_h = take<uint16_t>(64 * 256); wsf_l = take<uint16_t>(64 * 256);
+      wst_h = take<uint16_t>((size_t)H0 * 64 * ldt); wst_l = take<uint16_t>((size_t)H0 * 64 * ldt);
+      xmap = planes(pp * Hm * Wm * 4);
+    }
     Z1 = take<float>(pp * H1 * W1 * 64);
     coef1 = take<float>(4 * 64);
     A1 = planes(pp * H2 * W2 * 64);
     amax1 = take<uint8_t>(pp * H2 * W2 * 64);
-    size_t gmax = pp * H2 * W2 * 64, part_max = crw_rn_conv_part_floats(P, H1 * W1, 64);
+    size_t gmax = pp * H2 * W2 * 64, part_max = std::max(crw_rn_conv_part_floats(P, H1 * W1, 64), (size_t)rn_stem16_blocks() * 8 * 128);
     for (int i = 0; i < 4; ++i) {
       const Blk &b = blk[i];
       const size_t n = pp * b.hout * b.wout * b.cout;
@@ -120,14 +130,15 @@ struct Plan {
     dz1 = planes(pp * H1 * W1 * 64);
     for (int i = 0; i < 4; ++i) g[i] = take<float>(gmax);
     gA = take<float>(gmax);
-    dX0 = take<float>(pp * H0 * 64);
+    dX0 = stem16 ? nullptr : take<float>(pp * H0 * 64);
     // weight-gradient slabs: the largest of any layer
     auto need = [&](int mode, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int k, int s, int pad) {
       RnWgradArgs a;
       if (rn_make_wgrad(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, k, k, s, pad) != CRW_OK) { ok = false; return; }
       wgrad_bytes = std::max(wgrad_bytes, (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4);
     };
-    need(RN_MODE_STEM_FWD, Hm, Wm, 4, H1, W1, 64, 7, 2, 3);
+    if (stem16) wgrad_bytes = (size_t)rn_stem16_blocks() * 4 * 224 * 64 * 4;
+    else need(RN_MODE_STEM_FWD, Hm, Wm, 4, H1, W1, 64, 7, 2, 3);
     need(RN_MODE_FWD, 1, 1, 512, 1, 1, FEAT, 1, 1, 0);
     size_t bnb = 0;
     for (int i = 0; i < 4; ++i) {
@@ -219,12 +230,23 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
   auto rv = [&](int i) { return run_var ? run_var[i] : nullptr; };
 
   // stem: fc0 + bn0 + relu0 -> 4-channel map; 7x7/2 convolution + statistics; bn1 + relu + max-pool
-  CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, s));
-  CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
-                             pl.xmap.lo, pl.stem, pl.stem_ws, s));
-  CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1, pl.part));
-  CRW_TRY(launch_rn_bn_stats(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1),
-                             momentum, eps, pl.coef1, pl.stats_ws, s));
+  if (pl.stem16) {
+    CRW_TRY(launch_rn_pack_stem_frag(prm[4], pl.w16f, pl.w16t, s));
+    CRW_TRY(launch_rn_stem_stats(x, P, cin, h, w, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.stem, pl.stem_ws, s));
+    {
+      Timed t(s, 0, RN_MODE_STEM_FWD, 24, 24, 4, pl.H1, pl.W1, 64, 7, 2, 3);
+      CRW_TRY(launch_rn_stem16_fwd(x, P, cin, pl.stem, pl.w16f, pl.Z1, pl.part, s));
+    }
+    CRW_TRY(launch_rn_bn_stats(pl.part, rn_stem16_blocks() * 8, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1), momentum, eps,
+                               pl.coef1, pl.stats_ws, s));
+  } else {
+    CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, s));
+    CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
+                               pl.xmap.lo, pl.stem, pl.stem_ws, s));
+    CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1, pl.part));
+    CRW_TRY(launch_rn_bn_stats(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1),
+                               momentum, eps, pl.coef1, pl.stats_ws, s));
+  }
   CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, pl.amax1, s));
 
   Planes A = pl.A1;
@@ -305,6 +327,19 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   }
   // max-pool + bn1, stem convolution, stem
   CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.amax1, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
+  if (pl.stem16) {
+    {
+      Timed t(s, 1, RN_MODE_STEM_FWD, 24, 24, 4, pl.H1, pl.W1, 64, 7, 2, 3);
+      CRW_TRY(launch_rn_stem16_wgrad(x, P, cin, pl.stem, pl.dz1.hi, pl.dz1.lo, (float *)pl.wgrad_ws, s));
+      CRW_TRY(launch_rn_stem_slab_reduce((const float *)pl.wgrad_ws, rn_stem16_blocks() * 4, grads[4], s));
+    }
+    {
+      Timed t(s, 0, RN_MODE_STEM_BWD, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3);
+      CRW_TRY(launch_rn_stem16_bwd(x, P, cin, pl.stem, prm[0], prm[1], pl.w16t, pl.dz1.hi, pl.dz1.lo, pl.stem_part, s));
+    }
+    return launch_rn_stem_bwd_finalize(pl.stem_part, rn_stem16_blocks() * 8, cin, pl.stem, prm[0], prm[1], grads[0], grads[1], grads[2],
+                                       grads[3], pl.stem_ws, s);
+  }
   CRW_TRY(wgrad(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.dz1, grads[4], pl.wgrad_ws));
   CRW_TRY(conv(s, RN_MODE_STEM_BWD, P, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3, pl.dz1, pl.wst_h, pl.wst_l, nullptr, pl.dX0, nullptr));
   CRW_TRY(launch_rn_stem_bwd(pl.dX0, x, pl.stem, prm[0], prm[1], P, cin, h, w, 64, grads[0], grads[1], grads[2], grads[3], pl.stem_ws, s));

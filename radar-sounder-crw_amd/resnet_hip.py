@@ -4,15 +4,15 @@ hand-written HIP kernels of csrc/resnet_gemm.hip + csrc/resnet_bn.hip, through t
 Schedule of one training step for 16x16 patches (P patches; every convolution is a matrix product across patches, every
 BatchNorm runs on batch statistics exactly like ``nn.BatchNorm2d`` in train mode and updates its running statistics):
 
-    stem     fc0 (1x1, padding 1) + bn0 + relu0 -> zero-padded 4-channel 24x24 map          crw_rn_stem_fwd
-    conv1    7x7/2 (K = 8 kernel rows x 32) -> Z1 [P,81,64] + statistics                     crw_rn_conv mode 2, crw_rn_bn_stats
+    stem     bn0 statistics from the moments of x; fc0 + bn0 + relu0 + 7x7/2 convolution, a patch per wave (the 3-channel map
+             lives in LDS only) -> Z1 [P,81,64] + statistics                                 crw_rn_stem_stats, crw_rn_stem16_fwd, crw_rn_bn_stats_rows
     pool     relu(bn1(Z1)) -> 3x3/2 max-pool -> A1 [P,25,64]                                 crw_rn_bn_pool
     layer1-4 conv3x3 -> bn -> relu -> conv3x3 -> bn (+ 1x1/2 shortcut conv -> bn | identity) -> relu
                                                                                              crw_rn_conv mode 0, crw_rn_bn_stats, crw_rn_bn_apply
     head     global average pool of the 1x1 map (identity) + linear 512 -> 128               crw_rn_conv mode 0 (1x1) + bias
 
-and the mirror image backwards (crw_rn_bn_bwd, crw_rn_conv mode 1, crw_rn_wgrad, crw_rn_pool_bwd, crw_rn_conv mode 3,
-crw_rn_stem_bwd).  No PyTorch / MIOpen convolution or batch-norm call is made on this path.
+and the mirror image backwards (crw_rn_bn_bwd, crw_rn_conv mode 1, crw_rn_wgrad, crw_rn_pool_bwd, crw_rn_stem16_wgrad,
+crw_rn_stem16_bwd).  No PyTorch / MIOpen convolution or batch-norm call is made on this path.
 """
 import torch
 
@@ -88,11 +88,18 @@ class HipResnetFn(torch.autograd.Function):
             raise RuntimeError(f"HIP Resnet path: unsupported patch size {h}x{w}")
         sv = {"geo": (P, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm), "x": x, "blocks": blocks}
 
-        # ---- stem
-        wstem = H.rn_pack_stem(body.conv1.weight, h, w)
-        xmap, stem = H.rn_stem_fwd(x, net.fc0, net.bn0, Hm, Wm, mom)
-        Z1, part = H.rn_conv(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1), 64, (7, 7), 2, 3, xmap, wstem[:2], stats=True)
-        coef1 = H.rn_bn_stats(part, P, H1 * W1, body.bn1, mom)
+        # ---- stem: 16 x 16 patches on the patch-per-wave kernels (no map in HBM), other sizes on the gathered product
+        if (h, w) == (16, 16):
+            wstem = H.rn_pack_stem16(body.conv1.weight)
+            stem = H.rn_stem_stats(x, net.fc0, net.bn0, mom)
+            Z1, part = H.rn_stem16_fwd(x, stem, wstem[0])
+            coef1 = H.rn_bn_stats_rows(part, P * H1 * W1, body.bn1, mom)
+            xmap = None
+        else:
+            wstem = H.rn_pack_stem(body.conv1.weight, h, w)
+            xmap, stem = H.rn_stem_fwd(x, net.fc0, net.bn0, Hm, Wm, mom)
+            Z1, part = H.rn_conv(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1), 64, (7, 7), 2, 3, xmap, wstem[:2], stats=True)
+            coef1 = H.rn_bn_stats(part, P, H1 * W1, body.bn1, mom)
         A, amax = H.rn_bn_pool(Z1, coef1, P, H1, W1, 64)
         sv.update(wstem=wstem, xmap=xmap, stem=stem, Z1=Z1, coef1=coef1, amax=amax)
 
@@ -175,9 +182,13 @@ class HipResnetFn(torch.autograd.Function):
         # max-pool + bn1, stem convolution, stem
         dz1, dg, db = H.rn_pool_bwd(g1, g2, sv["amax"], sv["Z1"], sv["coef1"], P, H1, W1, 64)
         grads["model.bn1.weight"], grads["model.bn1.bias"] = dg, db
-        grads["model.conv1.weight"] = H.rn_wgrad(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1, 64), (7, 7), 2, 3, sv["xmap"], dz1)
-        dX0, _ = H.rn_conv(H.RN_STEM_BWD, P, (H1, W1, 64), (H0, 1), 64, (7, 7), 2, 3, dz1, sv["wstem"][2:])
-        dw0, db0, dg, db = H.rn_stem_bwd(dX0, sv["x"], sv["stem"], net.fc0.weight.detach(), net.fc0.bias.detach())
+        if sv["xmap"] is None:
+            grads["model.conv1.weight"] = H.rn_stem16_wgrad(sv["x"], sv["stem"], dz1)
+            dw0, db0, dg, db = H.rn_stem16_bwd(sv["x"], sv["stem"], net.fc0.weight.detach(), net.fc0.bias.detach(), sv["wstem"][1], dz1)
+        else:
+            grads["model.conv1.weight"] = H.rn_wgrad(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1, 64), (7, 7), 2, 3, sv["xmap"], dz1)
+            dX0, _ = H.rn_conv(H.RN_STEM_BWD, P, (H1, W1, 64), (H0, 1), 64, (7, 7), 2, 3, dz1, sv["wstem"][2:])
+            dw0, db0, dg, db = H.rn_stem_bwd(dX0, sv["x"], sv["stem"], net.fc0.weight.detach(), net.fc0.bias.detach())
         grads["fc0.weight"], grads["fc0.bias"], grads["bn0.weight"], grads["bn0.bias"] = dw0, db0, dg, db
         ctx.sv = None
         return (None, None) + tuple(grads[k] for k in ctx.names)
