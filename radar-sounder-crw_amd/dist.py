@@ -23,6 +23,13 @@ def init_from_env(backend=None):
     # rehearsal of the N > 1 control flow on a ONE-GPU box (tests / tools only): every rank on device 0, exchange over gloo
     # (RCCL refuses two ranks on one device).  CRW_DIST_REHEARSAL=1 python -m torch.distributed.run --nproc-per-node 2 bench.py ...
     if os.environ.get("CRW_DIST_REHEARSAL"):
+        # never silently: leaked into a real multi-GPU launch this would pile every rank onto device 0 over gloo
+        if world > 1 and torch.cuda.is_available() and torch.cuda.device_count() >= world and os.environ["CRW_DIST_REHEARSAL"] != "force":
+            raise RuntimeError(f"CRW_DIST_REHEARSAL is set but this node has {torch.cuda.device_count()} GPUs for {world} ranks: "
+                               "unset it for a real run (or set CRW_DIST_REHEARSAL=force)")
+        if rank == 0:
+            print("[dist] CRW_DIST_REHEARSAL: every rank on GPU 0, exchange over gloo (control-flow rehearsal, not a measurement)",
+                  flush=True)
         backend, local = "gloo", 0
     if world > 1 and not dist.is_initialized():
         if backend is None:

@@ -84,11 +84,16 @@ def segment(dataset, seg, encoder, lp, nclasses, seq_length, patch_size, overlap
                 continue
             small = T - change
             px = small * (W - ow)
-            try:  # like the reference, a correction that fails is skipped silently
+            try:  # like the reference, a correction that fails on its DATA (shape / index errors) is skipped silently ...
                 seq = dataset.get_smaller_item(idx[t], small).to(device)  # first `small` columns; shortens the dataset
                 seg_ref = seg[:, rg_len * t + rg_len - px:rg_len * t + rg_len - px + W]
                 pred, _, _ = propagate(seq, seg_ref, encoder, lp, nclasses, pos_embed, use_last=False)
                 maps[t][:, rg_len - px:] = _upsample(pred, rows, px)
+            except RuntimeError as e:
+                # ... but a failure of the HIP path (crw_hip._check: launch failure, workspace, GPU fault) or of the device is not
+                # a data problem: the reference's bare `except` would hide a poisoned device context behind an uncorrected map
+                if "failed: CRW_" in str(e) or "HIP" in str(e) or "hip" in str(e) or "CUDA" in str(e):
+                    raise
             except Exception:
                 pass
 

@@ -22,8 +22,8 @@ class _Affinity(torch.autograd.Function):
     they only save `walk_loss` a pass over A)."""
 
     @staticmethod
-    def forward(ctx, emb, tau):
-        A, ehat, norm, stats = crw_hip.affinity_fwd(emb.contiguous().float(), tau)
+    def forward(ctx, emb, tau, want_stats=True):
+        A, ehat, norm, stats = crw_hip.affinity_fwd(emb.contiguous().float(), tau, want_stats=want_stats)
         ctx.save_for_backward(ehat, norm)
         ctx.tau = tau
         if stats is None:
@@ -34,7 +34,7 @@ class _Affinity(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dA, _dstats=None):
         ehat, norm = ctx.saved_tensors
-        return crw_hip.affinity_bwd(dA.contiguous(), ehat, norm, ctx.tau), None
+        return crw_hip.affinity_bwd(dA.contiguous(), ehat, norm, ctx.tau), None, None
 
 
 class _WalkLoss(torch.autograd.Function):
@@ -54,7 +54,7 @@ class _WalkLoss(torch.autograd.Function):
 
 def affinity(emb, tau):
     """emb [B,T,N,C] (raw encoder output) -> logits A [B,T-1,N,N]; differentiable."""
-    return _Affinity.apply(emb, float(tau))[0]
+    return _Affinity.apply(emb, float(tau), False)[0]  # no statistics: neither their epilogue work nor their workspace
 
 
 def affinity_with_stats(emb, tau):

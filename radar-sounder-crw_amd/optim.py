@@ -23,7 +23,29 @@ class FlatAdam:
             o += p.numel()
         self.m, self.v, self.t = torch.zeros_like(self.flat), torch.zeros_like(self.flat), 0
 
+    def _check_views(self):
+        """the parameters must still be the views of ``self.flat`` made at construction: ``module.to()/.float()/.cuda()`` or
+        ``load_state_dict(assign=True)`` re-bind ``p.data`` and the step would then update a dead buffer without an error"""
+        params = self.bucket.params
+        first, last = params[0], params[-1]
+        end = self.flat.data_ptr() + 4 * (self.flat.numel() - last.numel())
+        if first.data_ptr() != self.flat.data_ptr() or last.data_ptr() != end or sum(p.numel() for p in params) != self.flat.numel():
+            raise RuntimeError("FlatAdam: the module's parameters no longer alias the optimizer's flat buffer (moved / re-assigned "
+                               "after FlatAdam was built?) -- rebuild the FlatGradBucket and FlatAdam")
+
     def step(self):
         """after ``bucket.all_reduce_mean()``: the flat gradient is complete."""
+        self._check_views()
         self.t += 1
         crw_hip.adam_step(self.flat, self.bucket.flat, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+
+    def state_dict(self):
+        """moments, step count and hyper-parameters (checkpoint / resume, like ``torch.optim.Adam.state_dict``)"""
+        return {"m": self.m.clone(), "v": self.v.clone(), "t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        if sd["m"].numel() != self.flat.numel():
+            raise ValueError("FlatAdam.load_state_dict: moment buffers of another parameter set")
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.t, self.lr, self.betas, self.eps = int(sd["t"]), float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])

@@ -171,6 +171,29 @@ def test_affinity_tiles_and_fused_statistics(hip, B, T, N, C, tau):
     torch.testing.assert_close(demb.cpu().double(), want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
 
 
+@pytest.mark.parametrize("N,C,tau", [(300, 128, 0.01), (512, 128, 0.01), (256, 64, 0.05)])
+def test_affinity_both_arithmetics_vs_fp64(hip, N, C, tau, monkeypatch):
+    """From 256 nodes on the affinity build runs on three-term bf16 splits (csrc/gemm_f32.hip `affinity_on_bf16`) unless
+    CRW_AFFINITY_F32=1 forces the fp32 MFMA: both paths against fp64 at tau = 0.01, where 1 / tau amplifies the error of the
+    logits that feed the softmaxes -- logits within 2e-5, the walk's loss within 1e-6 of each other."""
+    g = torch.Generator().manual_seed(N)
+    emb = (torch.randn(1, 1, N, C, generator=g) + 0.6 * torch.randn(1, 4, N, C, generator=g)).float().cuda()
+    eh = emb.double() / emb.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    A_ref = (torch.einsum("btnc,btmc->btnm", eh[:, :-1], eh[:, 1:]) / tau)
+    dA = torch.randn(A_ref.shape, generator=g).float().cuda()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CRW_AFFINITY_F32", mode)
+        A, ehat, norm, stats = hip.affinity_fwd(emb, tau)
+        err = (A.double() - A_ref).abs().max().item()
+        assert err <= 1e-4, (mode, err)  # logits up to 1 / tau = 100: 1e-6 of that
+        loss, _, _ = hip.walk_fwd(A, stats=stats)
+        out[mode] = (A, loss.item(), hip.affinity_bwd(dA, ehat, norm, tau), err)
+    assert not torch.equal(out["0"][0], out["1"][0]), "the two arithmetics should differ in the last bits (is the switch live?)"
+    assert abs(out["0"][1] - out["1"][1]) <= 1e-6 * max(1.0, abs(out["1"][1]))
+    torch.testing.assert_close(out["0"][2], out["1"][2], rtol=1e-4, atol=1e-4 * out["1"][2].abs().max().item())
+
+
 def test_no_cycle_T2(hip):
     import model as crw_model
     g = load_golden("walk_T2_nocycle")
@@ -265,8 +288,9 @@ def test_training_trajectory_matches_oracle(hip):
     enc.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
     net = crw_model.CRW(enc, tau, False).cuda()
     net.train(True)
+    import optim as crw_optim
     bucket = crw_dist.FlatGradBucket(net.parameters(), lazy=True)
-    opt = torch.optim.Adam(net.parameters(), lr=lr, fused=True)
+    opt = crw_optim.FlatAdam(bucket, lr=lr)  # what train.py / bench.py use (crw_adam_step on the flat parameter buffer)
     seq = dev(g["seq"])
     got = []
     for _ in range(steps):
@@ -696,6 +720,34 @@ def test_propagate_matches_reference(hip, name):
     np.testing.assert_allclose(xent.numpy(), g["xent"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["labelprop_trunc_T14N10", "labelprop_last_T20N24"])
+def test_propagate_with_a_foreign_label_propagation_object(hip, name):
+    """`utils.propagate` with an `lp` that only offers the reference's frame-by-frame `predict(feats, masks, curr_feat)` protocol
+    (src/imported/labelprop.py:67; no `propagate_all`): the fallback branch that stacks features / masks like src/utils.py:148-160
+    must give the reference's label map too."""
+    import utils as crw_utils
+    from imported.labelprop import LabelPropVOS_CRW
+    g = load_golden(name)
+    T, N, C = g["emb"].shape
+    cfg = dict(CXT_SIZE=int(g["cxt_size"]), RADIUS=int(g["radius"]), TEMP=float(g["temp"]), KNN=int(g["knn"]))
+
+    class PredictOnly:  # the reference's interface and nothing more
+        def __init__(self, inner):
+            self.inner, self.calls = inner, 0
+
+        def predict(self, feats, masks, curr_feat):
+            self.calls += 1
+            assert len(feats) == len(masks) == self.calls and curr_feat.shape == (1, C, N, 1) and masks[0].shape[2:] == (N, 1)
+            return self.inner.predict(feats, masks, curr_feat)
+
+    lp = PredictOnly(LabelPropVOS_CRW(cfg))
+    seq = dev(g["emb"]).reshape(T, N, C // 4, 4)
+    pred, xent, _ = crw_utils.propagate(seq, dev(g["seg_ref"]), _Flatten(), lp, int(g["nclasses"]), False, bool(g["use_last"]))
+    assert lp.calls == T - 1
+    assert np.array_equal(pred.cpu().numpy(), g["pred"]), f"{(pred.cpu().numpy() != g['pred']).sum()} labels differ"
+    np.testing.assert_allclose(xent.numpy(), g["xent"], rtol=1e-4, atol=1e-4)
+
+
 def test_predict_frame_by_frame_equals_batched(hip):
     from imported.labelprop import LabelPropVOS_CRW
     g = load_golden("labelprop_trunc_T14N10")
@@ -991,7 +1043,7 @@ def test_train_entrypoint_two_steps_vs_oracle(hip, tmp_path):
         assert (upd - upd_ref).norm() <= 0.1 * upd_ref.norm() + 1e-9, k
 
 
-def _cnn_labelprop_audit(hip, H, W, T, cfg, M=4, seed=9):
+def _cnn_labelprop_audit(hip, H, W, T, cfg, M=4, seed=9, train_steps=0):
     """Label propagation with the real CNN encoder at 32x32 patches, overlap (24,0) (BASELINE config 5 geometry): the
     HIP pipeline (tiled conv trunk -> normalise -> top-k -> gather) against (a) the fp32 oracle fed with the SAME
     normalised features, free-running, and (b) the fp64 teacher-forced tie audit (oracle.labelprop_tie_audit):
@@ -1008,7 +1060,24 @@ def _cnn_labelprop_audit(hip, H, W, T, cfg, M=4, seed=9):
     rows = N * 8 + 24
     seg = (torch.arange(rows)[:, None] * M // rows).float().repeat(1, 32)
     torch.manual_seed(11)
-    enc = crw_encoder.CNN(False).cuda().eval()
+    enc = crw_encoder.CNN(False).cuda()
+    if train_steps:  # a TRAINED encoder: the cycle loss pulls the nodes' features apart (affinities no longer near-uniform)
+        import model as crw_model
+        import dist as crw_dist
+        import optim as crw_optim
+        net = crw_model.CRW(enc, 0.01, False).cuda()
+        net.train(True)
+        bucket = crw_dist.FlatGradBucket(net.parameters(), lazy=True)
+        opt = crw_optim.FlatAdam(bucket, lr=1e-3)
+        items = crw_dataset.RGDataset.synthetic(H, 2048, 16, (32, 32), (24, 0), seed=seed + 1)
+        batch = torch.stack([items[i] for i in range(0, len(items), max(1, len(items) // 4))][:4]).cuda()
+        for _ in range(train_steps):
+            bucket.zero()
+            loss, _ = net(batch)
+            loss.backward()
+            bucket.all_reduce_mean()
+            opt.step()
+    enc.eval()
     lp = LabelPropVOS_CRW(cfg)
     pred, xent, _ = crw_utils.propagate(seq.cuda(), seg.cuda(), enc, lp, M, False, False)
     assert pred.shape == (N, T)
@@ -1049,6 +1118,14 @@ def test_propagate_with_cnn_at_mcords_size_vs_oracle(hip):
     RADIUS 10, TEMP 0.1, KNN 20 (scripts/test/test_all.py:27-30), random-init CNN (near-uniform affinities = the
     hardest case for ties)."""
     _cnn_labelprop_audit(hip, 410, 8192, 256, dict(CXT_SIZE=80, RADIUS=10, TEMP=0.1, KNN=20), seed=11)
+
+
+def test_propagate_with_trained_cnn_at_mcords_size_is_exact(hip):
+    """BASELINE config 5 at full size again, with an encoder that has TRAINED (Adam steps on the cycle loss: the nodes' features
+    separate, the top-k boundaries and class margins move away from the 1e-7 rounding level): the free-running HIP label map
+    must equal the oracle's outright -- no appeal to ties."""
+    free, audit = _cnn_labelprop_audit(hip, 410, 8192, 256, dict(CXT_SIZE=80, RADIUS=10, TEMP=0.1, KNN=20), seed=11, train_steps=30)
+    assert free == 0, (free, audit)
 
 
 def test_shared_column_encoding_two_radargrams(hip):
