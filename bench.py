@@ -42,6 +42,9 @@ def parse():
                          "bf16 = HIP kernels, plain bf16 operands; torch = PyTorch-ROCm (MIOpen) fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of --steps steps is run this many times; value / ms_per_step = the MEDIAN repeat "
+                         "(min / max on the line); every repeat is bracketed by barrier + synchronize like a single one")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket the conv kernels of the timed steps with HIP events (A/B of their overhead)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
@@ -353,11 +356,34 @@ def bench_labelprop(args):
     for _ in range(max(1, args.warmup)):
         pred, xent, _ = run()
     torch.cuda.synchronize()
+    import crw_hip
+    if not args.no_events:
+        crw_hip.KERNEL_EVENTS = {}  # HIP events around every map-convolution call of the timed passes, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pred, xent, _ = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    kernels = []
+    if crw_hip.KERNEL_EVENTS:
+        ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+        P, mh, mw = T * N, 26, 26  # 32 x 32 patches -> 26 x 26 maps after the front end
+        for (kind, cin, cout), pairs in ev.items():
+            if kind != "fwd_map":
+                continue
+            kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
+            alg = 2.0 * P * mh * mw * cin * cout * 9
+            # executed: 4 full 10 x 10 tiles on 7 row tiles + 5 edge tiles (10 x 6, 6 x 10, 6 x 6) on 4 row tiles of 16 pixels, 3 MFMAs per product
+            ex = 2.0 * P * (4 * 7 + 5 * 4) * 16 * cin * cout * 9 * 3
+            kernels.append({"kernel": f"conv3x3_kernel<3,{cin},{cout},0,8,MAP> (+bias+ReLU), two launches: full tiles / small edge tiles",
+                            "bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                            "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                            "mfma_executed_frac": ex / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], "traffic": None,
+                            "launch_us": kms * 1e3, "launches_per_step": len(pairs) // args.steps, "timed_launches": len(pairs),
+                            "algorithmic_flops_per_launch": alg,
+                            "note": "achieved = algorithmic fp32-equivalent flops (2 * P * 26 * 26 * cin * cout * 9, P = 12288 patches) / mean "
+                                    "HIP-event time of the layer's launches inside the timed passes"})
+        kernels.sort(key=lambda k: -k["launch_us"])
     # label propagation alone (features resident), the part the HIP kernels own
     with torch.no_grad():
         feats = crw_hip_normalize(enc, seq, T, N)
@@ -393,7 +419,7 @@ def bench_labelprop(args):
                       "cpu_baseline": {"value": W / dcpu, "unit": "radargram columns/s", "kind": "port", "cores": torch.get_num_threads(),
                                        "sample": f"oracle labelprop (numpy) on the same features, one pass, {dcpu:.2f} s"},
                       "label_agreement_with_oracle": match, "label_mismatches_not_ties": audit["not_ties"],
-                      "tie_audit": audit}), flush=True)
+                      "tie_audit": audit, **({"roofline": kernels[0], "roofline_kernels": kernels} if kernels else {})}), flush=True)
 
 
 def crw_hip_normalize(enc, seq, T, N):
@@ -477,18 +503,22 @@ def main():
         crw_hip.KERNEL_EVENTS = {}  # HIP events around every conv launch of the timed steps, on the launch stream
         if args.model == 1 and getattr(enc, "hip_convs", None):
             crw_hip.rn_timing(True)  # the Resnet pass is driven from native code: it records its own events (crw_rn_timing_*)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+    rep_elapsed = []
+    for _ in range(max(1, args.repeats)):  # each repeat: EXACTLY --steps steps between barrier + synchronize, MAX over ranks
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = t.item()
+        rep_elapsed.append(el)
+    elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]  # the median repeat is the one reported
     final_loss = loss.item()
 
     if rank == 0:
@@ -497,6 +527,9 @@ def main():
             "metric": "radargram columns/sec (CRW fwd+bwd)", "value": cols_per_step * world / (elapsed / args.steps),
             "unit": "radargram columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "repeats": {"n": len(rep_elapsed), "what": "value / ms_per_step are the median of n timed regions of `steps` steps each",
+                        "ms_per_step_min": min(rep_elapsed) / args.steps * 1e3, "ms_per_step_max": max(rep_elapsed) / args.steps * 1e3,
+                        "ms_per_step_all": [e / args.steps * 1e3 for e in rep_elapsed]},
             "dtype": {"bf16x3": "f32 (conv2-5 multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; everything else fp32)",
                       "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else ("bf16x3" if getattr(enc, "hip_convs", None) else "torch")],
             "data": "synthetic",
@@ -515,7 +548,7 @@ def main():
                 key = ("rn_conv" if rec.kind == 0 else "rn_wgrad", rec.mode, *list(rec.g), rec.k, rec.stride, rec.pad)
                 ev.setdefault(key, []).append(rec.ms)
             crw_hip.rn_timing(False)
-            kernels = resnet_event_kernels(ev, B * T * N, args.steps)
+            kernels = resnet_event_kernels(ev, B * T * N, args.steps * max(1, args.repeats))
         if crw_hip.KERNEL_EVENTS:
             # per-kernel durations measured live over the timed region (HIP events on the launch stream)
             ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
@@ -541,7 +574,7 @@ def main():
                                 "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
                                 "mfma_executed_tflops": alg * split * pad / (kms * 1e-3) / 1e12,
                                 "mfma_executed_frac": alg * split * pad / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                                "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // args.steps,
+                                "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // (args.steps * max(1, args.repeats)),
                                 "timed_launches": len(pairs),
                                 "note": "achieved = algorithmic (fp32-equivalent) flops / mean HIP-event time of this kernel's "
                                         "launches INSIDE the timed steps (events recorded on the launch stream); "
@@ -554,9 +587,23 @@ def main():
                             "frac": pfl / (pms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], "traffic": None,
                             "launch_us": pms * 1e3, "shape": f"n={Np} batch={B}x3",
                             "note": "launch-latency bound at the reference-default node count"})
-        # HBM traffic per launch from the committed PMC passes over this same command (rocprofv3 cannot run inside bench)
+        # HBM traffic per launch from the committed PMC passes over this same command (rocprofv3 cannot run inside bench).  The
+        # constants are keyed by kernel NAME, so they would go stale silently when a kernel changes and keeps its name: they are
+        # attached only where the live in-step event time of the kernel is within 5 % of the duration recorded beside them.
+        def pmc_fresh(k, rec):
+            stored = rec.get("duration_us")
+            if not stored:
+                return False
+            ok = abs(k["launch_us"] - stored) <= 0.05 * stored
+            if not ok:
+                k["traffic"] = None
+                k["traffic_note"] = (f"committed PMC constants NOT attached: live in-step launch time {k['launch_us']:.1f} us differs by more "
+                                     f"than 5 % from the {stored} us recorded with them (profiles/r02_pmc_in_step.json) -- re-run "
+                                     "tools/r02_pmc_run.sh + tools/pmc_report.py")
+            return ok
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_in_step_traffic.json")))["kernels"]
+            dur = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_in_step.json")))["kernels"]
             for k in kernels:
                 m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
                 if not m or args.convs != "bf16x3" or B * T * N != 16128:  # the passes ran at the default workload
@@ -566,7 +613,7 @@ def main():
                         f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4, false>") if "wgrad" in k["kernel"] else
                        f"conv3x3_kernel<3, {cout}, {cin}, 1, {4 if cin == 32 else 8}, false>" if "bwd-data" in k["kernel"] else
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
-                if key in pmc:
+                if key in pmc and pmc_fresh(k, dur.get(key, {})):
                     k["traffic"] = pmc[key]["hbm_bytes"]
                     k["traffic_note"] = ("HBM bytes per launch INSIDE the step, committed PMC passes profiles/r02_pmc_in_step_traffic.json: "
                                          "reads = 2*1024*FETCH_SIZE (gfx950 correction) + writes = 1024*WRITE_SIZE; read/algorithmic = "
@@ -583,7 +630,7 @@ def main():
                         f"conv3x3_wgrad_kernel<3, {cin}, {cout}, {min(cin, 64)}, 4, false>") if "wgrad" in k["kernel"] else
                        f"conv3x3_kernel<3, {cout}, {cin}, 1, {4 if cin == 32 else 8}, false>" if "bwd-data" in k["kernel"] else
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false>")
-                if key in util:
+                if key in util and pmc_fresh(k, util[key]):
                     k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
                     k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
                     k["pmc_note"] = ("committed PMC pass over this same command (profiles/r02_pmc_in_step.json): "

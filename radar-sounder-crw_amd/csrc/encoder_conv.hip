@@ -212,6 +212,9 @@ struct ConvArgs {
   long long *stamps;         // diagnostic builds only: [grid][5] s_memtime at phase boundaries (else null)
   // MAP variant only: planes are feature maps [P][mh][mw][C] of any size, a workgroup computes one 10x10 output tile
   int mh, mw, tiles_x, tiles_y;
+  // ... the tiles of this launch: tile_list[0..ncls) (a launch takes the tiles of one class: full ones, or the small edge tiles)
+  int ncls;
+  unsigned char tile_list[64];
 };
 
 // One workgroup = one patch, NW waves (4 or 8).  With 8 waves a wave owns one 16-channel output tile
@@ -230,8 +233,14 @@ template <int CIN, int COUT, int NW, bool MAP>
 constexpr int conv_waves_per_simd() {
   return (!MAP && NW == 8 && CIN <= 64 && COUT <= 64) ? 6 : NW / 2;
 }
-template <int SPLIT, int CIN, int COUT, int MODE, int NW, bool MAP = false>
+// MTL (MAP only): row tiles of 16 that a tile of this launch needs.  Edge tiles of a map hold tw x th < 100 in-map pixels
+// (26 x 26 maps: 10 x 6, 6 x 10, 6 x 6); those with at most 64 go to an MTL = 4 launch whose MFMA rows are dealt to the in-map
+// pixels only (row i -> pixel (i / tw, i % tw)): 28 + 20 = 48 row tiles per 26 x 26 map instead of 63 (r02 cfg5: conv5 at 0.134 of
+// the roof against 0.20 on 10 x 10 maps).  MTL = MT keeps the 10-wide row order (pixels outside the map are computed and dropped).
+template <int SPLIT, int CIN, int COUT, int MODE, int NW, bool MAP = false, int MTL = MT>
 __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>())) void conv3x3_kernel(ConvArgs a) {
+  static_assert(MAP || MTL == MT, "MTL is a MAP parameter");
+  constexpr bool REMAP = MTL < MT;
   constexpr int NT = NW * 64;
   constexpr int NPL = (SPLIT == 3) ? 2 : 1;
   constexpr int CMAX = CIN > COUT ? CIN : COUT;
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>()
   constexpr int WN = (COUT / 16 >= NW) ? NW : COUT / 16;  // waves across the output channels
   constexpr int WM = NW / WN;                             // waves across the pixel row tiles
   constexpr int NTW = COUT / 16 / WN;                     // 16-wide column tiles per wave
-  constexpr int MTW = (MT + WM - 1) / WM;                 // row tiles per wave and patch (tile wm + WM*k)
+  constexpr int MTW = (MTL + WM - 1) / WM;                // row tiles per wave and patch (tile wm + WM*k)
   constexpr int KCH = CIN / 32;                           // 32-deep k-steps per tap
   // rows dealt out by bank residue (slot_pixel) where a wave owns all 7 row tiles; with row tiles split over waves
   // (64 / 32 output channels at 8 waves) the wave-uniform tile index costs the short epilogue more than the reads gain
@@ -253,12 +262,20 @@ __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>()
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   int p0 = blockIdx.x, ty0 = 0, tx0 = 0;  // patch; MAP: origin of this workgroup's output tile in the map
+  int tw = IMG_W, npix_live = NPIX, tw_recip = 0, gap_slot = 0;
   if constexpr (MAP) {
-    const int ntile = a.tiles_x * a.tiles_y, tile = blockIdx.x % ntile;
-    p0 = blockIdx.x / ntile;
+    const int tile = a.tile_list[blockIdx.x % a.ncls];
+    p0 = blockIdx.x / a.ncls;
     ty0 = (tile / a.tiles_x) * IMG_W;
     tx0 = (tile % a.tiles_x) * IMG_W;
+    gap_slot = p0 * (a.tiles_x * a.tiles_y) + tile;
+    if constexpr (REMAP) {
+      tw = min(IMG_W, a.mw - tx0);
+      npix_live = tw * min(IMG_W, a.mh - ty0);  // <= 16 MTL by the launcher's choice of class
+      tw_recip = 65536 / tw + 1;                // (i * tw_recip) >> 16 == i / tw for i < 112, tw <= 10
+    }
   }
+  (void)tw; (void)npix_live; (void)tw_recip; (void)gap_slot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
 
@@ -317,7 +334,12 @@ __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>()
   int abase[MTW];
 #pragma unroll
   for (int k = 0; k < MTW; ++k) {
-    if constexpr (!PERM) {
+    if constexpr (REMAP) {
+      int i = 16 * (wm + WM * k) + r16;
+      if (i >= npix_live) i = 0;  // dummy rows recompute pixel 0 and are dropped in the epilogue
+      const int y = (i * tw_recip) >> 16;
+      abase[k] = (y * PAD_W + (i - y * tw)) * RSI + 16 * g;
+    } else if constexpr (!PERM) {
       int i = 16 * (wm + WM * k) + r16;
       if (i >= NPIX) i = 0;  // dummy rows recompute pixel 0 and are dropped in the epilogue
       abase[k] = ((i / IMG_W) * PAD_W + (i % IMG_W)) * RSI + 16 * g;
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>()
       abase[k] = (y * PAD_W + x) * RSI + 16 * g;
     }
   }
-  auto tile_live = [&](int k) { return WM == 1 || wm + WM * k < MT; };  // wave-uniform
+  auto tile_live = [&](int k) { return WM == 1 || wm + WM * k < MTL; };  // wave-uniform
   auto step_off = [&](int step) {
     const int tap = step / KCH, cc = step % KCH;
     return ((tap / 3) * PAD_W + (tap % 3)) * RSI + 64 * cc;
@@ -449,7 +471,12 @@ __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>()
           int i = 16 * (wm + WM * k) + 4 * g + r;
           bool valid = i < NPIX;  // also false for the tiles a wave does not own (wm + WM k >= 7)
           int pp = 0;
-          if constexpr (!PERM) {
+          if constexpr (REMAP) {  // row i of the tile = in-map pixel (i / tw, i % tw); canonical pixel id y * 10 + x from here on
+            valid = i < npix_live && wm + WM * k < MTL;
+            const int y = (i * tw_recip) >> 16;
+            i = y * IMG_W + (i - y * tw);
+            if (valid) pp = interior_pp(i);
+          } else if constexpr (!PERM) {
             if (valid) pp = interior_pp(i);
           } else {
             // slot_pixel(tile, 4 g + r) split into a wave-uniform part (tile, r) and the per-lane terms of the lane group g
@@ -493,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, (conv_waves_per_simd<CIN, COUT, NW, MAP>()
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (g == 0) {
-          if constexpr (MAP) a.gap[(long)blockIdx.x * COUT + co_w + 16 * j + r16] = s;  // per-tile sum; the caller reduces
+          if constexpr (MAP) a.gap[(long)gap_slot * COUT + co_w + 16 * j + r16] = s;  // per-tile sum; the caller reduces
           else a.gap[(long)p * COUT + co_w + 16 * j + r16] = s * (1.0f / NPIX);
         }
       }
@@ -1356,21 +1383,40 @@ int launch_conv_nw(const ConvArgs &a, hipStream_t s) {
   return check_launch();
 }
 
-template <int SPLIT, int CIN, int COUT, int MODE = 0>
-int launch_conv_map(const ConvArgs &a, hipStream_t s) {
+constexpr int MT_SMALL = 4;  // row tiles of the small-edge-tile launch (tiles with at most 64 in-map pixels)
+
+template <int SPLIT, int CIN, int COUT, int MODE, int MTL>
+int launch_conv_map_cls(const ConvArgs &a, hipStream_t s) {
   constexpr int CMAX = CIN > COUT ? CIN : COUT, NW = (SPLIT == 3 ? 8 : 4);
   const size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * NPAD * row_stride<CMAX>();
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW, true>,
+    if (hipFuncSetAttribute((const void *)conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW, true, MTL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW, true>), dim3(a.P * a.tiles_x * a.tiles_y), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<SPLIT, CIN, COUT, MODE, NW, true, MTL>), dim3(a.P * a.ncls), dim3(NW * 64), lds, s, a);
   return check_launch();
+}
+
+// two launches: the tiles with more than 64 in-map pixels on 7 row tiles, the small edge tiles on 4
+template <int SPLIT, int CIN, int COUT, int MODE = 0>
+int launch_conv_map(const ConvArgs &a0, hipStream_t s) {
+  const int ntile = a0.tiles_x * a0.tiles_y;
+  if (ntile > 64) return CRW_EINVAL;  // maps up to 80 x 80
+  ConvArgs big = a0, small = a0;
+  big.ncls = small.ncls = 0;
+  for (int t = 0; t < ntile; ++t) {
+    const int th = std::min(IMG_W, a0.mh - (t / a0.tiles_x) * IMG_W), tw = std::min(IMG_W, a0.mw - (t % a0.tiles_x) * IMG_W);
+    if (tw * th > 16 * MT_SMALL) big.tile_list[big.ncls++] = (unsigned char)t;
+    else small.tile_list[small.ncls++] = (unsigned char)t;
+  }
+  if (big.ncls) CRW_TRY((launch_conv_map_cls<SPLIT, CIN, COUT, MODE, MT>(big, s)));
+  if (small.ncls) CRW_TRY((launch_conv_map_cls<SPLIT, CIN, COUT, MODE, MT_SMALL>(small, s)));
+  return CRW_OK;
 }
 
 template <int SPLIT, int CIN, int COUT, int MODE>
@@ -1497,7 +1543,7 @@ int crw_enc_conv3x3_map(int mode, int split, int P, int H, int W, int cin, int c
   if (mode == 1 && (gap_part || bias)) return CRW_EINVAL;
   const int tx = (W + IMG_W - 1) / IMG_W, ty = (H + IMG_W - 1) / IMG_W;
   if ((long)P * tx * ty > 0x7fffffffL) return CRW_EINVAL;
-  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap_part, nullptr, P, nullptr, H, W, tx, ty};
+  ConvArgs a{x_hi, x_lo, w_hi, w_lo, bias, mask_hi, y_hi, y_lo, y_f32, gap_part, nullptr, P, nullptr, H, W, tx, ty, 0, {}};
   hipStream_t s = (hipStream_t)stream;
 #define CRW_MAP_CASE(CI, CO, MODE) \
   if (mode == MODE && cin == CI && cout == CO) return split == 3 ? launch_conv_map<3, CI, CO, MODE>(a, s) : launch_conv_map<1, CI, CO, MODE>(a, s);
