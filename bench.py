@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket the conv kernels of the timed steps with HIP events (A/B of their overhead)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared", "dense"],
+    ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared", "dense", "train32"],
                     help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
                          "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder; labelprop: BASELINE "
                          "config 5, MCoRDS-shaped 410x8192 radargram, user-seed label propagation (utils.propagate); "
@@ -454,10 +454,13 @@ def main():
         import crw_hip
         crw_hip.lib()
         return bench_shared(args)
+    global OVERLAP, H_RG, W_RG, PATCH
     if args.workload == "dense":  # shape family D: same radargram, vertical patch stride 1 -> N = 497
-        global OVERLAP
         OVERLAP = (15, 0)
         args.no_probe = args.no_cpu_baseline = True
+    if args.workload == "train32":  # BASELINE config 5's geometry in TRAINING: 410 x 8192 radargram, 32 x 32 patches, overlap (24, 0)
+        H_RG, W_RG, PATCH, OVERLAP = 410, 8192, (32, 32), (24, 0)  # -> 8 items [T=32, N=48, 32x32]: the tiled ("map") kernels, fwd + bwd
+        args.no_probe = True
     import dist as crw_dist
     rank, world, local = crw_dist.init_from_env("nccl")
     if world > 1:  # the stand-alone probes (chain at n = 4096, walk alone) are single-GPU figures; the per-kernel
@@ -534,7 +537,7 @@ def main():
                       "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else ("bf16x3" if getattr(enc, "hip_convs", None) else "torch")],
             "data": "synthetic",
             "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
-                                   f"[T={T},N={N},16x16] (patch 16x16, overlap {OVERLAP}), tau={TAU}, "
+                                   f"[T={T},N={N},{PATCH[0]}x{PATCH[1]}] (patch {PATCH[0]}x{PATCH[1]}, overlap {OVERLAP}), tau={TAU}, "
                                    f"{'CNN' if args.model == 0 else 'Resnet'} encoder, fwd+bwd+all-reduce+Adam",
                        "columns_per_step_per_gpu": cols_per_step, "parallelism": f"dp{world} (independent sequences)",
                        "chain": "fp32 MFMA 16x16x4, prefix form",
@@ -554,19 +557,24 @@ def main():
             ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
             split = 3 if args.convs == "bf16x3" else 1
             P = B * T * N
-            names = {"fwd": "conv3x3_kernel fwd (bias+ReLU)", "bwd": "conv3x3_kernel bwd-data (+ReLU mask)",
+            mpx = (PATCH[0] - 6) * (PATCH[1] - 6)  # pixels of the conv3-5 feature map (100 for 16 x 16 patches)
+            names = {"fwd_map": "conv3x3_kernel<MAP> fwd (bias+ReLU), full + small-edge tile launches",
+                     "bwd_map": "conv3x3_kernel<MAP> bwd-data (+ReLU mask)", "wgrad_map": "conv3x3_wgrad_kernel<MAP> (+ slice sum)",
+                     "fwd": "conv3x3_kernel fwd (bias+ReLU)", "bwd": "conv3x3_kernel bwd-data (+ReLU mask)",
                      "front_fwd": "front_fwd_kernel (conv1-pool-conv2-pool, saves pool1 planes + pooling codes)",
                      "front_bwd": "front_bwd_saved_kernel (+ slice sum)",
                      "wgrad": "conv3x3_wgrad2_kernel / conv3x3_wgrad_kernel (+ slice sum)"}
             for (kind, cin, cout), pairs in sorted(ev.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
                 kms = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs)
-                alg = 2.0 * P * 100 * cin * cout * 9  # algorithmic flops of one pass over one layer
+                alg = 2.0 * P * (mpx if kind.endswith("_map") else 100) * cin * cout * 9  # algorithmic flops of one pass over one layer
                 if kind.startswith("front"):  # conv1 (196 outputs x 8 ch x 25 cin taps) + conv2 (121 x 32 x 200), x2 for the backward
                     alg = 2.0 * P * (196 * 8 * 25 * cin + 121 * 32 * 200) * (2 if kind == "front_bwd" else 1)
                 # MFMA padding of the pixel dim: forward / backward-data run 7 row tiles of 16 per patch; the streamed weight gradient
                 # (128 output channels) takes its k-steps of 32 pixels over the whole pixel stream of a slice, the first-generation
                 # kernel (conv3's 64 output channels) 10 k-steps per 3 patches
                 pad = (1.0 if cout == 128 else (10 * 32 / 3) / 100.0) if kind == "wgrad" else 112.0 / 100.0
+                if kind.endswith("_map"):  # 26 x 26 maps: 4 full tiles x 7 + 5 edge tiles x 4 row tiles of 16 (weight gradient: 9 units x 4 k-steps of 32)
+                    pad = ((4 * 7 + 5 * 4) * 16 if kind != "wgrad_map" else 9 * 128) / float(mpx) if mpx == 676 else 1.0
                 if kind.startswith("front"):
                     pad = 1.0
                 kernels.append({"kernel": f"{names[kind]} cin={cin} cout={cout}", "bound": "mfma",
