@@ -17,6 +17,13 @@ struct RnConvArgs {
   float *out;                   // [Mpad][ldc]: group g writes columns [g*N, (g+1)*N)
   float *part;                  // per-tile column sums / sums of squares [mtiles*2][G][N] float2, or null
   const float *bias;            // [N] or null
+  int accumulate;               // epilogue adds the tile to what `out` holds (the second gradient arriving at a junction)
+  // backward-data only: BatchNorm-backward sums of the layer that consumes this gradient, from the epilogue (all [Mpad][ldc] like
+  // `out`): red_mask = hi plane of that layer's output activation (ReLU gate), red_z (+ red_zd: the shortcut's) = its raw
+  // convolution output(s), red_coef / red_coefd = their coef[4][N]; red_part [mtiles*2][G][2|3][N] partial sums.  null: off
+  const uint16_t *red_mask;
+  const float *red_z, *red_coef, *red_zd, *red_coefd;
+  float *red_part;
   long b_group_stride;          // RN_MODE_STEM_BWD: elements between the weight planes of consecutive groups
   int lda, ldb, ldc, N, G, mtiles;
   int mode;
@@ -58,7 +65,7 @@ size_t rn_bn_bwd_ws_bytes(int P, int npix, int C);
 int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
                      const float *coef_d, int P, int Ppad, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi,
                      uint16_t *dzd_lo, float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws,
-                     hipStream_t s);
+                     hipStream_t s, const float *ext_part = nullptr, int ext_rows = 0);
 size_t rn_pool_bwd_ws_bytes(int P, int H, int W, int C);
 int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int Ppad, int H,
                        int W, int C, uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s);

