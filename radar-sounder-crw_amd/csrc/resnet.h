@@ -81,6 +81,17 @@ int launch_rn_stem_bwd_finalize(const float *part, int rows, int cin, const floa
 int launch_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
                        int ldx, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, hipStream_t s);
 int launch_rn_pack_conv(const float *w, int cout, int cin, int T, uint16_t *fh, uint16_t *fl, uint16_t *bh, uint16_t *bl, hipStream_t s);
+constexpr int RN_MAX_PACK_JOBS = 16;
+struct RnPackJob {
+  const float *w;
+  uint16_t *fh, *fl, *bh, *bl;
+  int cout, cin, T, first_block;
+};
+struct RnPackJobs {
+  RnPackJob job[RN_MAX_PACK_JOBS];
+  int n;
+};
+int launch_rn_pack_all(RnPackJobs &jobs, hipStream_t s);
 int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, uint16_t *fh, uint16_t *fl, uint16_t *th, uint16_t *tl,
                         hipStream_t s);
 int launch_rn_split(const float *x, long rows, long rows_pad, int C, uint16_t *hi, uint16_t *lo, hipStream_t s);

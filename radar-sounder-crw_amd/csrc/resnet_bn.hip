@@ -351,24 +351,35 @@ __device__ inline Oct pool_grad8(const float *__restrict__ d1, const float *__re
   Oct g;
 #pragma unroll
   for (int k = 0; k < 8; ++k) g.v[k] = 0.f;
-  const int oy0 = iy < 1 ? 0 : iy / 2, oy1 = min(Ho - 1, (iy + 1) / 2);  // windows with 2 oy - 1 <= iy <= 2 oy + 1
+  const int oy0 = iy < 1 ? 0 : iy / 2, oy1 = min(Ho - 1, (iy + 1) / 2);  // windows with 2 oy - 1 <= iy <= 2 oy + 1: one or two rows
   const int ox0 = ix < 1 ? 0 : ix / 2, ox1 = min(Wo - 1, (ix + 1) / 2);
-  for (int oy = oy0; oy <= oy1; ++oy)
-    for (int ox = ox0; ox <= ox1; ++ox) {
-      const long e = ((p * Ho + oy) * Wo + ox) * C + c;
-      const int code = (iy - 2 * oy + 1) * 3 + (ix - 2 * ox + 1);
-      const uint2 a = *reinterpret_cast<const uint2 *>(amax + e);
-      Oct d = load8(d1 + e);
-      if (d2) {
-        const Oct h = load8(d2 + e);
+  // the (at most) 2 x 2 candidate windows: all loads issued up front with clamped indices, validity applied afterwards (loads
+  // under data-dependent loop bounds are waited for one by one)
+  uint2 am[4];
+  Oct d[4];
+  bool ok[4];
+  int code[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d.v[k] += h.v[k];
-      }
+  for (int w = 0; w < 4; ++w) {
+    const int oy = oy0 + (w >> 1), ox = ox0 + (w & 1);
+    ok[w] = oy <= oy1 && ox <= ox1;
+    const int cy = min(oy, oy1), cx = min(ox, ox1);
+    const long e = ((p * Ho + cy) * Wo + cx) * C + c;
+    code[w] = (iy - 2 * cy + 1) * 3 + (ix - 2 * cx + 1);
+    am[w] = *reinterpret_cast<const uint2 *>(amax + e);
+    d[w] = load8(d1 + e);
+    if (d2) {
+      const Oct h = load8(d2 + e);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int am = (int)(((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xff);
-        g.v[k] += am == code ? d.v[k] : 0.f;
-      }
+      for (int k = 0; k < 8; ++k) d[w].v[k] += h.v[k];
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int a = (int)(((k < 4 ? am[w].x : am[w].y) >> (8 * (k & 3))) & 0xff);
+      g.v[k] += (ok[w] && a == code[w]) ? d[w].v[k] : 0.f;
     }
 #pragma unroll
   for (int k = 0; k < 8; ++k) g.v[k] = (z.v[k] * scale.v[k] + shift.v[k]) > 0.f ? g.v[k] : 0.f;
@@ -629,6 +640,27 @@ __global__ __launch_bounds__(256) void rn_pack_conv_kernel(const float *__restri
   }
 }
 
+// every convolution / linear weight of the network in ONE launch (12 launches of the kernel above were 115 us of a 5.5 ms
+// step): block = one output channel of one layer -- its cin * T source values are contiguous, read 16 bytes per lane
+__global__ __launch_bounds__(256) void rn_pack_all_kernel(RnPackJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
+  const RnPackJob &q = jobs.job[j];
+  const int co = blockIdx.x - q.first_block;
+  const int n = q.cin * q.T;
+  const float *src = q.w + (long)co * n;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int ci = e / q.T, t = e - ci * q.T;
+    const float v = src[e];
+    const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+    const long f = ((long)co * q.T + t) * q.cin + ci, b = ((long)ci * q.T + t) * q.cout + co;
+    q.fh[f] = h;
+    q.fl[f] = l;
+    q.bh[b] = h;
+    q.bl[b] = l;
+  }
+}
+
 // stem 7x7/2 weights w1 [64][3][7][7]:
 //   forward planes [64][256]: k = ky * 32 + kx * 4 + c (zero for ky = 7, kx = 7, c = 3)
 //   Toeplitz planes [H0][64][ldt] for the backward-data GEMM: row iy, column n = ix * 3 + c (zero for n >= 3 * W0),
@@ -838,6 +870,17 @@ int launch_rn_stem_bwd_finalize(const float *part, int rows, int cin, const floa
 
 int launch_rn_pack_conv(const float *w, int cout, int cin, int T, uint16_t *fh, uint16_t *fl, uint16_t *bh, uint16_t *bl, hipStream_t s) {
   hipLaunchKernelGGL(rn_pack_conv_kernel, dim3(grid_for((long)cout * cin * T)), dim3(256), 0, s, w, cout, cin, T, fh, fl, bh, bl);
+  return check_launch();
+}
+
+int launch_rn_pack_all(RnPackJobs &jobs, hipStream_t s) {
+  int blocks = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    jobs.job[i].first_block = blocks;
+    blocks += jobs.job[i].cout;
+  }
+  if (jobs.n < 1 || jobs.n > RN_MAX_PACK_JOBS) return CRW_EINVAL;
+  hipLaunchKernelGGL(rn_pack_all_kernel, dim3(blocks), dim3(256), 0, s, jobs);
   return check_launch();
 }
 

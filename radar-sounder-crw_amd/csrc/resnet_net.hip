@@ -239,6 +239,21 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
   auto rm = [&](int i) { return run_mean ? run_mean[i] : nullptr; };
   auto rv = [&](int i) { return run_var ? run_var[i] : nullptr; };
 
+  // all convolution / linear weights -> hi / lo planes (forward and backward-data layouts), one launch
+  {
+    RnPackJobs jobs{};
+    auto add = [&](const float *wsrc, const Wpack &d, int cout, int cin_, int T) {
+      jobs.job[jobs.n++] = RnPackJob{wsrc, d.fh, d.fl, d.bh, d.bl, cout, cin_, T, 0};
+    };
+    for (int i = 0; i < 4; ++i) {
+      const Blk &b = pl.blk[i];
+      add(prm[b.pbase], pl.r[i].wa, b.cout, b.cin, 9);
+      add(prm[b.pbase + 3], pl.r[i].wb, b.cout, b.cout, 9);
+      if (b.down) add(prm[b.pbase + 6], pl.r[i].wd, b.cout, b.cin, 1);
+    }
+    add(prm[40], pl.wfc, FEAT, 512, 1);
+    CRW_TRY(launch_rn_pack_all(jobs, s));
+  }
   // stem: fc0 + bn0 + relu0 -> 4-channel map; 7x7/2 convolution + statistics; bn1 + relu + max-pool
   if (pl.stem16) {
     CRW_TRY(launch_rn_pack_stem_frag(prm[4], pl.w16f, pl.w16t, s));
@@ -266,15 +281,12 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
     const int npix = b.hout * b.wout, rows = (pl.Ppad / 128) * 2 * npix;
     const double cnt = (double)P * npix;
     const float *const *q = prm + b.pbase;
-    CRW_TRY(launch_rn_pack_conv(q[0], b.cout, b.cin, 9, r.wa.fh, r.wa.fl, r.wa.bh, r.wa.bl, s));
-    CRW_TRY(launch_rn_pack_conv(q[3], b.cout, b.cout, 9, r.wb.fh, r.wb.fl, r.wb.bh, r.wb.bl, s));
     CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, A, r.wa.fh, r.wa.fl, nullptr, r.Za, pl.part));
     CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[1], q[2], rm(b.bn), rv(b.bn), momentum, eps, r.ca, pl.stats_ws, s));
     CRW_TRY(launch_rn_bn_apply(r.Za, r.ca, nullptr, nullptr, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aa.hi, r.Aa.lo, s));
     CRW_TRY(conv(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, r.wb.fh, r.wb.fl, nullptr, r.Zb, pl.part));
     CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[4], q[5], rm(b.bn + 1), rv(b.bn + 1), momentum, eps, r.cb, pl.stats_ws, s));
     if (b.down) {
-      CRW_TRY(launch_rn_pack_conv(q[6], b.cout, b.cin, 1, r.wd.fh, r.wd.fl, r.wd.bh, r.wd.bl, s));
       CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, A, r.wd.fh, r.wd.fl, nullptr, r.Zd, pl.part));
       CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[7], q[8], rm(b.bn + 2), rv(b.bn + 2), momentum, eps, r.cd, pl.stats_ws, s));
       CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, r.Zd, r.cd, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
@@ -284,7 +296,6 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
     A = r.Aout;
   }
   // head: the average pool of the 1 x 1 map is the identity; linear 512 -> 128 with bias
-  CRW_TRY(launch_rn_pack_conv(prm[40], FEAT, 512, 1, pl.wfc.fh, pl.wfc.fl, pl.wfc.bh, pl.wfc.bl, s));
   CRW_TRY(conv(s, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, A, pl.wfc.fh, pl.wfc.fl, prm[41], pl.outp, nullptr));
   if (hipMemcpyAsync(out, pl.outp, (size_t)P * FEAT * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
     g_last_hip_error = (int)hipGetLastError();
