@@ -428,9 +428,12 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
 
   auto stage = [&](int kt, int buf) {
     char *base = lds + buf * C::STAGE;
-    const int ktp = a.ktiles_p * (64 / BK);  // k-tiles per pair
-    const int pair = kt / ktp;
-    const int p0 = (kt - pair * ktp) * BK;
+    // k-tiles in PATCH-major order (tile kt = patch chunk kt / npairs, pair kt % npairs): a slice is then a contiguous range of
+    // patches with all their pixels, so the workgroups of the 9 taps of a slice -- co-scheduled on one XCD -- re-read the same
+    // ~1 MB of planes from its L2.  (Pair-major order read every pixel plane once per tap from HBM: PMC 1.26 GB per launch of
+    // layer1's weight gradient against 0.21 GB of tensors, at 6.5 TB/s.)
+    const int chunk = kt / npairs, pair = kt - chunk * npairs;
+    const int p0 = chunk * BK;
     const int oa = pa[pair], ob = pb[pair];
 #pragma unroll
     for (int i = 0; i < C::PA; ++i) {
