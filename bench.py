@@ -186,6 +186,24 @@ def resnet_event_kernels(ev, P, steps):
                     "note": "achieved = algorithmic (fp32-equivalent, in-map taps only) flops / mean HIP-event time of this kernel's launches "
                             "INSIDE the timed steps; every product is 3 bf16 MFMAs on hi/lo operand pairs"})
     out.sort(key=lambda k_: -k_["launch_us"] * k_["launches_per_step"])
+    # HBM traffic of layer1's weight gradient (the dominant matrix-core kernel of the step) from the committed in-step PMC passes
+    # (profiles/r03_pmc_resnet.json: rn_wgrad_kernel<64, 64, 32> is launched exactly twice per step, for layer1's two convolutions),
+    # attached only while the kernel still takes the time recorded with the counters (+ its slab sum inside the event bracket)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_resnet.json")))["kernels"]
+        rec = pmc["crw::rn_wgrad_kernel<64, 64, 32>"]
+        for k in out:
+            if k["kernel"].startswith("rn_wgrad_kernel 5x5x64 -> 5x5x64") and P == 16128:
+                per_launch_us = rec["us_per_step"] / rec["launches_per_step"]
+                if abs(k["launch_us"] - per_launch_us - 10.0) <= 0.08 * per_launch_us:
+                    k["traffic"] = (rec["hbm_read_MB"] + rec["hbm_write_MB"]) * 1e6 / rec["launches_per_step"]
+                    k["traffic_note"] = ("HBM bytes per launch inside the step (profiles/r03_pmc_resnet.json: 2*1024*FETCH_SIZE + 1024*WRITE_SIZE, "
+                                         "separate passes); algorithmic: both operands' planes once = 2 * P * 25 * 64 * 4 B = 206 MB")
+                else:
+                    k["traffic_note"] = (f"committed PMC constants NOT attached: live {k['launch_us']:.1f} us vs {per_launch_us:.1f} us "
+                                         "(+ ~10 us slab sum) recorded with them")
+    except Exception:
+        pass
     return out
 
 
