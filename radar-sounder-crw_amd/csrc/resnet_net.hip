@@ -63,7 +63,7 @@ struct Plan {
   float *part, *redpart;
   double *stats_ws;
   void *stem_ws;
-  Planes dO, dzb, dza, dzd, dz1;
+  Planes dO, dzb[4], dza[4], dzd[4], dz1;  // per block: the weight gradients read them on a side stream while the chain moves on
   float *g[2], *gA, *dX0;
   void *wgrad_ws, *bnbwd_ws, *poolbwd_ws, *colsum_ws;
   size_t wgrad_bytes = 0;
@@ -127,7 +127,10 @@ struct Plan {
     stats_ws = take<double>((size_t)64 * 2 * 512);
     stem_ws = take<char>(rn_stem_ws_bytes());
     dO = planes(pp * FEAT);
-    dzb = planes(gmax); dza = planes(gmax); dzd = planes(gmax);
+    for (int i = 0; i < 4; ++i) {
+      const size_t n = pp * blk[i].hout * blk[i].wout * blk[i].cout;
+      dzb[i] = planes(n); dza[i] = planes(n); dzd[i] = blk[i].down ? planes(n) : Planes{nullptr, nullptr};
+    }
     dz1 = planes(pp * H1 * W1 * 64);
     for (int i = 0; i < 2; ++i) g[i] = take<float>(gmax);
     gA = take<float>(gmax);
@@ -194,6 +197,34 @@ struct Red {
   const float *z = nullptr, *coef = nullptr, *zd = nullptr, *coefd = nullptr;
   float *part = nullptr;
 };
+
+// ---- side stream: the weight gradients leave the serial backward chain ---------------------------------------------------
+// The chain bn_bwd -> backward-data product -> bn_bwd -> ... is serial and carries ~50 us-scale merge / finalize launches that
+// leave the chip nearly idle; the weight gradients depend only on planes the chain has already produced, so they run on a second
+// HIP stream beside it (fork by event after the apply pass that writes their dZ planes, join at the end of the pass).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  bool ok = true;
+  hipStream_t get() {
+    if (!stream && ok && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+    return stream;
+  }
+  hipEvent_t event() {
+    if (used == ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ok = false; return nullptr; }
+      ev.push_back(e);
+    }
+    return ev[used++];
+  }
+  // everything enqueued on `from` so far happens before what is enqueued on `to` from now on
+  bool order(hipStream_t from, hipStream_t to) {
+    hipEvent_t e = event();
+    return e && hipEventRecord(e, from) == hipSuccess && hipStreamWaitEvent(to, e, 0) == hipSuccess;
+  }
+} g_side;
 
 int conv(hipStream_t s, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int k, int stride, int pad, Planes a, const uint16_t *bh,
          const uint16_t *bl, const float *bias, float *out, float *part, bool accumulate = false, const Red &red = Red()) {
@@ -314,10 +345,17 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   if (!pl.ok) return CRW_EINVAL;
   if (ws_bytes < pl.off) return CRW_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  // weight gradients on the side stream (CRW_RN_STREAMS=0: everything on the caller's stream)
+  static const bool use_side = !(getenv("CRW_RN_STREAMS") && getenv("CRW_RN_STREAMS")[0] == '0');
+  hipStream_t sw = use_side ? g_side.get() : nullptr;
+  if (!sw) sw = s;
+  g_side.used = 0;
+  auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };  // side stream sees what the chain has produced
 
   // head
   CRW_TRY(launch_rn_split(dout, P, pl.Ppad, FEAT, pl.dO.hi, pl.dO.lo, s));
-  CRW_TRY(wgrad(s, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, pl.r[3].Aout, pl.dO, grads[40], pl.wgrad_ws));
+  CRW_TRY(fork());
+  CRW_TRY(wgrad(sw, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, pl.r[3].Aout, pl.dO, grads[40], pl.wgrad_ws));
   CRW_TRY(launch_rn_colsum(dout, P, FEAT, grads[41], pl.colsum_ws, s));
   // Gradients meet at every block output (main branch + shortcut): the first product writes, the second ADDS in its epilogue.
   // (The product that completes a gradient can also take the BatchNorm-backward sums of the layer it feeds in that epilogue --
@@ -339,44 +377,50 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
     float *gin = g == pl.g[0] ? pl.g[1] : pl.g[0];  // gradient of the block's input (= the previous block's output)
     const Planes Ain = i == 0 ? pl.A1 : pl.r[i - 1].Aout;
     // block output: bn2 (+ the shortcut's BatchNorm); an identity shortcut hands the masked gradient on in `gin`
-    CRW_TRY(launch_rn_bn_bwd(g, nullptr, r.Aout.hi, r.Zb, r.cb, r.Zd, r.cd, P, pl.Ppad, npix, b.cout, pl.dzb.hi, pl.dzb.lo, b.down ? pl.dzd.hi : nullptr,
-                             b.down ? pl.dzd.lo : nullptr, b.down ? nullptr : gin, gq[4], gq[5], b.down ? gq[7] : nullptr,
+    CRW_TRY(launch_rn_bn_bwd(g, nullptr, r.Aout.hi, r.Zb, r.cb, r.Zd, r.cd, P, pl.Ppad, npix, b.cout, pl.dzb[i].hi, pl.dzb[i].lo, b.down ? pl.dzd[i].hi : nullptr,
+                             b.down ? pl.dzd[i].lo : nullptr, b.down ? nullptr : gin, gq[4], gq[5], b.down ? gq[7] : nullptr,
                              b.down ? gq[8] : nullptr, pl.bnbwd_ws, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
-    CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, pl.dzb, gq[3], pl.wgrad_ws));
-    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, pl.dzb, r.wb.bh, r.wb.bl, nullptr, pl.gA, nullptr, false,
+    CRW_TRY(fork());
+    CRW_TRY(wgrad(sw, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, pl.dzb[i], gq[3], pl.wgrad_ws));
+    if (b.down) CRW_TRY(wgrad(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, Ain, pl.dzd[i], gq[6], pl.wgrad_ws));
+    CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, pl.dzb[i], r.wb.bh, r.wb.bl, nullptr, pl.gA, nullptr, false,
                  fuse_red ? Red{r.Aa.hi, r.Za, r.ca, nullptr, nullptr, pl.redpart} : Red()));
-    CRW_TRY(launch_rn_bn_bwd(pl.gA, nullptr, r.Aa.hi, r.Za, r.ca, nullptr, nullptr, P, pl.Ppad, npix, b.cout, pl.dza.hi, pl.dza.lo, nullptr, nullptr,
+    CRW_TRY(launch_rn_bn_bwd(pl.gA, nullptr, r.Aa.hi, r.Za, r.ca, nullptr, nullptr, P, pl.Ppad, npix, b.cout, pl.dza[i].hi, pl.dza[i].lo, nullptr, nullptr,
                              nullptr, gq[1], gq[2], nullptr, nullptr, pl.bnbwd_ws, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
-    CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, Ain, pl.dza, gq[0], pl.wgrad_ws));
+    CRW_TRY(fork());
+    CRW_TRY(wgrad(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, Ain, pl.dza[i], gq[0], pl.wgrad_ws));
     if (b.down) {
       // input gradient = main branch (written) + shortcut (added); the sum feeds the previous block's output BatchNorms
       const auto &rp = pl.r[i - 1];  // blocks 1..3 have the shortcut convolution, so i >= 1 here
-      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza, r.wa.bh, r.wa.bl, nullptr, gin, nullptr));
-      CRW_TRY(wgrad(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, Ain, pl.dzd, gq[6], pl.wgrad_ws));
-      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 1, b.stride, 0, pl.dzd, r.wd.bh, r.wd.bl, nullptr, gin, nullptr, true,
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza[i], r.wa.bh, r.wa.bl, nullptr, gin, nullptr));
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 1, b.stride, 0, pl.dzd[i], r.wd.bh, r.wd.bl, nullptr, gin, nullptr, true,
                    fuse_red ? Red{rp.Aout.hi, rp.Zb, rp.cb, rp.Zd, rp.cd, pl.redpart} : Red()));
     } else {
       // identity shortcut (layer1): `gin` holds the masked gradient of the block output; the main branch adds to it
-      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza, r.wa.bh, r.wa.bl, nullptr, gin, nullptr, true));
+      CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hin, b.win, b.cin, 3, b.stride, 1, pl.dza[i], r.wa.bh, r.wa.bl, nullptr, gin, nullptr, true));
     }
     g = gin;
   }
   float *g1 = g, *g2 = nullptr;
   // max-pool + bn1, stem convolution, stem
   CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.amax1, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
+  auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };  // the caller's stream waits for the side stream
   if (pl.stem16) {
+    CRW_TRY(fork());
     {
-      Timed t(s, 1, RN_MODE_STEM_FWD, 24, 24, 4, pl.H1, pl.W1, 64, 7, 2, 3);
-      CRW_TRY(launch_rn_stem16_wgrad(x, P, cin, pl.stem, pl.dz1.hi, pl.dz1.lo, (float *)pl.wgrad_ws, s));
-      CRW_TRY(launch_rn_stem_slab_reduce((const float *)pl.wgrad_ws, rn_stem16_blocks() * 4, grads[4], s));
+      Timed t(sw, 1, RN_MODE_STEM_FWD, 24, 24, 4, pl.H1, pl.W1, 64, 7, 2, 3);
+      CRW_TRY(launch_rn_stem16_wgrad(x, P, cin, pl.stem, pl.dz1.hi, pl.dz1.lo, (float *)pl.wgrad_ws, sw));
+      CRW_TRY(launch_rn_stem_slab_reduce((const float *)pl.wgrad_ws, rn_stem16_blocks() * 4, grads[4], sw));
     }
     {
       Timed t(s, 0, RN_MODE_STEM_BWD, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3);
       CRW_TRY(launch_rn_stem16_bwd(x, P, cin, pl.stem, prm[0], prm[1], pl.w16t, pl.dz1.hi, pl.dz1.lo, pl.stem_part, s));
     }
-    return launch_rn_stem_bwd_finalize(pl.stem_part, rn_stem16_blocks() * 8, cin, pl.stem, prm[0], prm[1], grads[0], grads[1], grads[2],
-                                       grads[3], pl.stem_ws, s);
+    CRW_TRY(launch_rn_stem_bwd_finalize(pl.stem_part, rn_stem16_blocks() * 8, cin, pl.stem, prm[0], prm[1], grads[0], grads[1], grads[2],
+                                        grads[3], pl.stem_ws, s));
+    return join();
   }
+  CRW_TRY(join());
   CRW_TRY(wgrad(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.dz1, grads[4], pl.wgrad_ws));
   CRW_TRY(conv(s, RN_MODE_STEM_BWD, P, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3, pl.dz1, pl.wst_h, pl.wst_l, nullptr, pl.dX0, nullptr));
   CRW_TRY(launch_rn_stem_bwd(pl.dX0, x, pl.stem, prm[0], prm[1], P, cin, h, w, 64, grads[0], grads[1], grads[2], grads[3], pl.stem_ws, s));
