@@ -60,8 +60,8 @@ struct Plan {
   Wpack wfc;
   float *outp;  // [Ppad][128]
   // scratch
-  float *part, *redpart;
-  double *stats_ws;
+  float *part, *part_d, *redpart;   // part_d / stats_ws_d: the shortcut branch computes beside the main one (side stream)
+  double *stats_ws, *stats_ws_d;
   void *stem_ws;
   Planes dO, dzb[4], dza[4], dzd[4], dz1;  // per block: the weight gradients read them on a side stream while the chain moves on
   float *g[2], *gA, *dX0;
@@ -123,8 +123,10 @@ struct Plan {
     wfc = wpack((size_t)FEAT * 512);
     outp = take<float>(pp * FEAT);
     part = take<float>(part_max);
+    part_d = take<float>(part_max);
     redpart = take<float>(part_max * 2);  // [rows][3][C] against [rows][C][2]
     stats_ws = take<double>((size_t)64 * 2 * 512);
+    stats_ws_d = take<double>((size_t)64 * 2 * 512);
     stem_ws = take<char>(rn_stem_ws_bytes());
     dO = planes(pp * FEAT);
     for (int i = 0; i < 4; ++i) {
@@ -269,8 +271,17 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
   hipStream_t s = (hipStream_t)stream;
   auto rm = [&](int i) { return run_mean ? run_mean[i] : nullptr; };
   auto rv = [&](int i) { return run_var ? run_var[i] : nullptr; };
+  // side stream: the weight packing runs beside the stem (which does not need it), each shortcut convolution + its statistics
+  // beside its block's main branch (CRW_RN_STREAMS=0: everything on the caller's stream)
+  static const bool use_side = !(getenv("CRW_RN_STREAMS") && getenv("CRW_RN_STREAMS")[0] == '0');
+  hipStream_t sw = use_side ? g_side.get() : nullptr;
+  if (!sw) sw = s;
+  g_side.used = 0;
+  auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };
+  auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };
 
   // all convolution / linear weights -> hi / lo planes (forward and backward-data layouts), one launch
+  CRW_TRY(fork());
   {
     RnPackJobs jobs{};
     auto add = [&](const float *wsrc, const Wpack &d, int cout, int cin_, int T) {
@@ -283,7 +294,7 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
       if (b.down) add(prm[b.pbase + 6], pl.r[i].wd, b.cout, b.cin, 1);
     }
     add(prm[40], pl.wfc, FEAT, 512, 1);
-    CRW_TRY(launch_rn_pack_all(jobs, s));
+    CRW_TRY(launch_rn_pack_all(jobs, sw));
   }
   // stem: fc0 + bn0 + relu0 -> 4-channel map; 7x7/2 convolution + statistics; bn1 + relu + max-pool
   if (pl.stem16) {
@@ -305,6 +316,7 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
   }
   CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, pl.amax1, s));
 
+  CRW_TRY(join());  // packed weights ready
   Planes A = pl.A1;
   for (int i = 0; i < 4; ++i) {
     const Blk &b = pl.blk[i];
@@ -312,14 +324,18 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
     const int npix = b.hout * b.wout, rows = (pl.Ppad / 128) * 2 * npix;
     const double cnt = (double)P * npix;
     const float *const *q = prm + b.pbase;
+    if (b.down) {  // shortcut: 1x1 / stride-2 convolution of the block input + its statistics, beside the main branch
+      CRW_TRY(fork());
+      CRW_TRY(conv(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, A, r.wd.fh, r.wd.fl, nullptr, r.Zd, pl.part_d));
+      CRW_TRY(launch_rn_bn_stats(pl.part_d, rows, b.cout, cnt, q[7], q[8], rm(b.bn + 2), rv(b.bn + 2), momentum, eps, r.cd, pl.stats_ws_d, sw));
+    }
     CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, A, r.wa.fh, r.wa.fl, nullptr, r.Za, pl.part));
     CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[1], q[2], rm(b.bn), rv(b.bn), momentum, eps, r.ca, pl.stats_ws, s));
     CRW_TRY(launch_rn_bn_apply(r.Za, r.ca, nullptr, nullptr, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aa.hi, r.Aa.lo, s));
     CRW_TRY(conv(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, r.wb.fh, r.wb.fl, nullptr, r.Zb, pl.part));
     CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[4], q[5], rm(b.bn + 1), rv(b.bn + 1), momentum, eps, r.cb, pl.stats_ws, s));
     if (b.down) {
-      CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, A, r.wd.fh, r.wd.fl, nullptr, r.Zd, pl.part));
-      CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[7], q[8], rm(b.bn + 2), rv(b.bn + 2), momentum, eps, r.cd, pl.stats_ws, s));
+      CRW_TRY(join());
       CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, r.Zd, r.cd, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
     } else {
       CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, nullptr, nullptr, A.hi, A.lo, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
