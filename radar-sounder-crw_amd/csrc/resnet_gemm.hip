@@ -255,44 +255,90 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two wo
     return v;
   };
   if constexpr (EPI == 2) {
+    // The tile goes through LDS (the ring is free now) and comes back row-contiguous: float4 stores of whole 128-byte lines and
+    // float4 / 8-byte loads of the consuming layer's Z and activation planes.  (Straight from the MFMA layout -- 4-byte
+    // accesses, 16 lanes per row segment -- the extra loads cost as much as the separate reduce pass they replace.)
+    constexpr int LDT = TN + 4;                   // row stride in floats: the four row groups of a wave hit disjoint banks
+    constexpr int TPR = TN / 4, RPP = 256 / TPR;  // threads per row (one float4 each), rows per pass
+    constexpr int NB = 4;                         // passes whose loads are in flight together
+    static_assert((64 / RPP) % NB == 0, "passes per half tile");
+    float *tile = reinterpret_cast<float *>(lds);
     const int nsum = a.red_zd ? 3 : 2;
+    __syncthreads();  // every wave has read its last fragments
+    {
+      const int gq = lane >> 4, c16 = lane & 15;
 #pragma unroll
-    for (int j = 0; j < C::FN; ++j) {
-      const int col = n0 + wn + 16 * j + (lane & 15);
-      const float mean = a.red_coef[2 * a.N + col], istd = a.red_coef[3 * a.N + col];
-      const float mean_d = a.red_zd ? a.red_coefd[2 * a.N + col] : 0.f, istd_d = a.red_zd ? a.red_coefd[3 * a.N + col] : 0.f;
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int i = 0; i < C::FM; ++i)
 #pragma unroll
-      for (int i = 0; i < C::FM; ++i) {
-        float prev[4], z[4], zd[4];
-        uint16_t mk[4];
+        for (int j = 0; j < C::FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // the four rows' loads together, then the arithmetic
-          const long idx = crow0 + (long)(16 * i + r) * a.ldc + 16 * j;
-          prev[r] = a.accumulate ? a.out[idx] : 0.f;
-          mk[r] = a.red_mask[idx];
-          z[r] = a.red_z[idx];
-          zd[r] = a.red_zd ? a.red_zd[idx] : 0.f;
+          for (int r = 0; r < 4; ++r) tile[(wm + 16 * i + 4 * gq + r) * LDT + wn + 16 * j + c16] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int c4 = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int col = n0 + 4 * c4;
+    const float4 mean = *reinterpret_cast<const float4 *>(a.red_coef + 2 * a.N + col);
+    const float4 istd = *reinterpret_cast<const float4 *>(a.red_coef + 3 * a.N + col);
+    float4 mean_d = float4{0.f, 0.f, 0.f, 0.f}, istd_d = mean_d;
+    if (a.red_zd) {
+      mean_d = *reinterpret_cast<const float4 *>(a.red_coefd + 2 * a.N + col);
+      istd_d = *reinterpret_cast<const float4 *>(a.red_coefd + 3 * a.N + col);
+    }
+    const long base = (long)m0 * a.ldc + (long)g * a.N + col;
+    float sums[2][3][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sums[h][k][e] = 0.f;
+#pragma unroll 1
+      for (int p0 = 0; p0 < 64 / RPP; p0 += NB) {
+        float4 prev[NB], z[NB], zd[NB];
+        uint2 mk[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const long idx = base + (long)(64 * h + (p0 + u) * RPP + rl) * a.ldc;
+          prev[u] = a.accumulate ? *reinterpret_cast<const float4 *>(a.out + idx) : float4{0.f, 0.f, 0.f, 0.f};
+          mk[u] = *reinterpret_cast<const uint2 *>(a.red_mask + idx);
+          z[u] = *reinterpret_cast<const float4 *>(a.red_z + idx);
+          zd[u] = a.red_zd ? *reinterpret_cast<const float4 *>(a.red_zd + idx) : float4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long idx = crow0 + (long)(16 * i + r) * a.ldc + 16 * j;
-          const float v = acc[i][j][r] + prev[r];
-          a.out[idx] = v;
-          const float gv = mk[r] != 0 ? v : 0.f;
-          s1 += gv;
-          s2 += gv * ((z[r] - mean) * istd);
-          s3 += gv * ((zd[r] - mean_d) * istd_d);
+        for (int u = 0; u < NB; ++u) {
+          const int row = 64 * h + (p0 + u) * RPP + rl;
+          float4 v = *reinterpret_cast<const float4 *>(tile + row * LDT + 4 * c4);
+          v.x += prev[u].x; v.y += prev[u].y; v.z += prev[u].z; v.w += prev[u].w;
+          *reinterpret_cast<float4 *>(a.out + base + (long)row * a.ldc) = v;
+          const float gv[4] = {(mk[u].x & 0xffffu) ? v.x : 0.f, (mk[u].x >> 16) ? v.y : 0.f, (mk[u].y & 0xffffu) ? v.z : 0.f,
+                               (mk[u].y >> 16) ? v.w : 0.f};
+          const float zz[4] = {z[u].x, z[u].y, z[u].z, z[u].w}, zzd[4] = {zd[u].x, zd[u].y, zd[u].z, zd[u].w};
+          const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, ii[4] = {istd.x, istd.y, istd.z, istd.w};
+          const float mmd[4] = {mean_d.x, mean_d.y, mean_d.z, mean_d.w}, iid[4] = {istd_d.x, istd_d.y, istd_d.z, istd_d.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sums[h][0][e] += gv[e];
+            sums[h][1][e] += gv[e] * ((zz[e] - mm[e]) * ii[e]);
+            sums[h][2][e] += gv[e] * ((zzd[e] - mmd[e]) * iid[e]);
+          }
         }
       }
-      s1 = colsum(s1);
-      s2 = colsum(s2);
-      s3 = colsum(s3);
-      if (lane < 16) {  // [row][nsum][N]: the layout of rn_bn_bwd_reduce_kernel's partials
-        a.red_part[(prow * nsum + 0) * a.N + col] = s1;
-        a.red_part[(prow * nsum + 1) * a.N + col] = s2;
-        if (nsum == 3) a.red_part[(prow * nsum + 2) * a.N + col] = s3;
-      }
+    }
+    __syncthreads();  // the tile has been read
+    float *red = tile;  // [2 halves][3 sums][RPP row lanes][TN]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        *reinterpret_cast<float4 *>(red + ((h * 3 + k) * RPP + rl) * TN + 4 * c4) =
+            float4{sums[h][k][0], sums[h][k][1], sums[h][k][2], sums[h][k][3]};
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * nsum * TN; o += 256) {  // [row][nsum][N]: the layout of rn_bn_bwd_reduce_kernel's partials
+      const int c = o % TN, k = (o / TN) % nsum, h = o / (TN * nsum);
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) t += red[((h * 3 + k) * RPP + q) * TN + c];
+      a.red_part[(((long)(mt * 2 + h) * a.G + g) * nsum + k) * a.N + n0 + c] = t;
     }
   } else if constexpr (EPI == 1) {
 #pragma unroll
@@ -334,17 +380,19 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two wo
 template <int TN, int BK, int NSTAGE, int EPI>
 int launch_conv_epi(const RnConvArgs &a, hipStream_t s) {
   using C = NNCfg<TN, BK, NSTAGE>;
+  constexpr size_t staged = (size_t)C::TM * (TN + 4) * 4;  // EPI 2 passes the output tile through LDS
+  constexpr size_t lds_bytes = (EPI == 2 && staged > C::LDS) ? staged : C::LDS;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)rn_conv_kernel<TN, BK, NSTAGE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)C::LDS) != hipSuccess) {
+                            (int)lds_bytes) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr_set = true;
   }
   const int total = a.mtiles * (a.N / TN) * a.G;
-  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE, EPI>), dim3(total), dim3(256), C::LDS, s, a);
+  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE, EPI>), dim3(total), dim3(256), lds_bytes, s, a);
   return check_launch();
 }
 

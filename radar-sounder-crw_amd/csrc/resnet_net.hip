@@ -374,10 +374,11 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   CRW_TRY(wgrad(sw, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, pl.r[3].Aout, pl.dO, grads[40], pl.wgrad_ws));
   CRW_TRY(launch_rn_colsum(dout, P, FEAT, grads[41], pl.colsum_ws, s));
   // Gradients meet at every block output (main branch + shortcut): the first product writes, the second ADDS in its epilogue.
-  // (The product that completes a gradient can also take the BatchNorm-backward sums of the layer it feeds in that epilogue --
-  // RnConvArgs::red_*, CRW_RN_FUSE_RED=1 -- but with the accumulator layout's 64-byte row pieces the extra mask / Z reads cost
-  // the 128-column products more than the separate reduce pass they replace: measured 6.8 against 5.6 ms per step.)
-  static const bool fuse_red = getenv("CRW_RN_FUSE_RED") != nullptr;
+  // The product that completes a gradient also takes the BatchNorm-backward sums of the layer it feeds in its epilogue
+  // (RnConvArgs::red_*): the tile goes through LDS and comes back row-contiguous, so the extra mask / Z reads are whole lines.
+  // The separate reduce pass (10 B per element re-read from HBM) disappears: 5.04 -> 4.8 ms per step.  CRW_RN_FUSE_RED=0 keeps it.
+  // (Straight from the accumulator layout -- 64-byte row pieces -- the same fusion measured SLOWER than the separate pass.)
+  static const bool fuse_red = !(getenv("CRW_RN_FUSE_RED") && getenv("CRW_RN_FUSE_RED")[0] == '0');
   const int rrows = pl.Ppad / 128 * 2;  // partial rows per group
   float *g = pl.g[0];                   // gradient of the current block's output
   {

@@ -3,6 +3,9 @@
 set -o pipefail
 O=gpurun_out/r03rn; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_resnet_hip.py -q -m gpu > $O/tests.log 2>&1; tail -1 $O/tests.log
+if [ -n "$TESTENV" ]; then  # the parity tests once more under an env knob, e.g. TESTENV=CRW_RN_FUSE_RED=1
+  timeout -k 10 600 env $TESTENV python -m pytest tests/test_resnet_hip.py -q -m gpu -k "resnet_hip or resnet_native" > $O/tests_env.log 2>&1; echo "$TESTENV: $(tail -1 $O/tests_env.log)"
+fi
 run() { timeout -k 10 300 env "$@" python bench.py --model 1 --no-probe --no-cpu-baseline > $O/bench_m1.log 2>&1; grep '^{' $O/bench_m1.log | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$*', 'ms/step %.3f' % d['ms_per_step'], 'loss', d['config']['loss'])
 for k in d.get('roofline_kernels', [])[:40]: print('   %-72s x%d %7.1f us  alg %.3f exec %.3f' % (k['kernel'][:72], k['launches_per_step'], k['launch_us'], k['frac'], k['mfma_executed_frac']))
