@@ -8,6 +8,7 @@
 // every plane (the GEMM epilogues then need no row predicate and the padded rows add nothing to any statistic).
 // A BatchNorm's coefficients travel as coef[4][C] = (scale = gamma * invstd, shift = beta - mean * scale, mean, invstd).
 #include "crw_common.h"
+#include <atomic>
 #include "resnet.h"
 
 namespace crw {
@@ -123,6 +124,110 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const double *__res
     run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
     run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
   }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums, merge in the last block
+// The same two-level sum in ONE launch: grid (channel blocks, R2 row blocks); a block adds its rows of in [R][NS sums][C] (or
+// [R][C][NS] when INTERLEAVED) into part2 [R2][NS][C] (doubles), takes a ticket for its channel block, and the block that draws the
+// last ticket merges the R2 rows -- in row order, whichever block it is: the result does not depend on the schedule -- and runs
+// the tail (BatchNorm coefficients / parameter gradients).  Saves the 6-8 us finalize launch behind every reduction of a step.
+constexpr int RN_TICKET_SLOTS = 64, RN_TICKET_BLOCKS = 32;  // consecutive launches use different slots (two streams run these)
+__device__ unsigned g_rn_tickets[RN_TICKET_SLOTS * RN_TICKET_BLOCKS];
+
+struct StatsTail {  // forward: sums (s, ss) -> coef (scale, shift, mean, invstd) + running statistics (see rn_bn_finalize_kernel)
+  double count;
+  const float *gamma, *beta;
+  float *run_mean, *run_var;
+  float momentum, eps;
+  float *coef;
+  __device__ void operator()(int c, int C, const double *s) const {
+    const double mean = s[0] / count;
+    double var = s[1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double scale = (double)gamma[c] * invstd;
+    coef[c] = (float)scale;
+    coef[C + c] = (float)((double)beta[c] - mean * scale);
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = (float)invstd;
+    if (run_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
+      run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
+    }
+  }
+};
+template <int NS>
+struct BwdTail {  // backward: sums (g, g xhat [, g xhat_d]) -> dbeta, dgamma [, the shortcut's] and the apply pass's constants
+  double count;
+  float *dgamma, *dbeta, *dgamma_d, *dbeta_d, *kc;
+  __device__ void operator()(int c, int C, const double *s) const {
+    dbeta[c] = (float)s[0];
+    dgamma[c] = (float)s[1];
+    kc[c] = (float)(s[0] / count);
+    kc[C + c] = (float)(s[1] / count);
+    if (NS == 3) {
+      dbeta_d[c] = (float)s[0];
+      dgamma_d[c] = (float)s[2];
+      kc[2 * C + c] = (float)(s[2] / count);
+    }
+  }
+};
+
+template <int NS, bool INTERLEAVED, class Tail>
+__global__ __launch_bounds__(1024) void rn_sums_tail_kernel(const float *__restrict__ in, int R, int C, int RB, double *part2,
+                                                            unsigned *tickets, Tail tail) {
+  __shared__ double sh[NS][16][64];
+  __shared__ unsigned ticket;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, W = NS * C;
+  const int r0 = blockIdx.y * RB, r1 = min(R, r0 + RB);
+  double acc[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) acc[n] = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 16)
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc[n] += (double)in[(long)r * W + (INTERLEAVED ? NS * c + n : n * C + c)];
+  }
+#pragma unroll
+  for (int n = 0; n < NS; ++n) sh[n][rl][cl] = acc[n];
+  __syncthreads();
+  if (rl < NS && c < C) {  // wave n adds the 16 row lanes of sum n in lane order
+    double tot = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) tot += sh[rl][l][cl];
+    // agent-scope (sc1) store: written through to where every XCD reads it.  (A device-scope __threadfence() here writes the
+    // XCD's L2 back once per wave: measured +0.8 ms per step.)
+    __hip_atomic_store(&part2[((long)blockIdx.y * NS + rl) * C + c], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been acknowledged ...
+  __syncthreads();                                   // ... for every wave of the block, before its ticket is drawn
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != gridDim.y - 1) return;
+  const int R2 = gridDim.y;
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    double a = 0.0;
+    if (c < C)
+      for (int r = rl; r < R2; r += 16) a += __hip_atomic_load(&part2[((long)r * NS + n) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh[n][rl][cl] = a;
+  }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double tot[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      double t = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) t += sh[n][l][cl];
+      tot[n] = t;
+    }
+    tail(c, C, tot);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the slot's next use
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm apply
@@ -724,6 +829,29 @@ inline unsigned grid_for(long n, int per_block = 256, long cap = 8192) {
 
 }  // namespace
 
+unsigned *rn_ticket_slot() {
+  static unsigned *base = nullptr;
+  static std::atomic<unsigned> next{0};
+  if (!base && hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_rn_tickets)) != hipSuccess) {
+    g_last_hip_error = (int)hipGetLastError();
+    return nullptr;
+  }
+  return base + (size_t)(next.fetch_add(1) % RN_TICKET_SLOTS) * RN_TICKET_BLOCKS;
+}
+
+// in [R][NS][C] (or [R][C][NS]) fp32 -> sums over R per channel, handed to `tail` by the last block; part2: 64 * NS * C doubles
+template <int NS, bool INTERLEAVED, class Tail>
+int rn_sums_tail(const float *in, int R, int C, double *part2, const Tail &tail, hipStream_t s) {
+  if ((C + 63) / 64 > RN_TICKET_BLOCKS) return CRW_EINVAL;
+  unsigned *tk = rn_ticket_slot();
+  if (!tk) return CRW_EHIP;
+  const int want = NS * C >= 256 ? 32 : 64;
+  const int RB = (R + want - 1) / want > 0 ? (R + want - 1) / want : 1;
+  const int R2 = (R + RB - 1) / RB;
+  hipLaunchKernelGGL((rn_sums_tail_kernel<NS, INTERLEAVED, Tail>), dim3((C + 63) / 64, R2), dim3(1024), 0, s, in, R, C, RB, part2, tk, tail);
+  return check_launch();
+}
+
 // in [R][W] fp32 -> ws (doubles) [R2][W]; returns R2
 int rn_rows_reduce(const float *in, int R, int W, double *ws, hipStream_t s) {
   // 32 block rows for wide inputs; narrow ones (the stem's 8 / 16 columns) get 64 so that more than a handful of blocks run
@@ -736,10 +864,8 @@ int rn_rows_reduce(const float *in, int R, int W, double *ws, hipStream_t s) {
 
 int launch_rn_bn_stats(const float *part, int R, int C, double count, const float *gamma, const float *beta, float *run_mean,
                        float *run_var, float momentum, float eps, float *coef, double *ws, hipStream_t s) {
-  const int R2 = rn_rows_reduce(part, R, 2 * C, ws, s);
-  hipLaunchKernelGGL(rn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, R2, C, count, gamma, beta, run_mean, run_var,
-                     momentum, eps, coef);
-  return check_launch();
+  const StatsTail tail{count, gamma, beta, run_mean, run_var, momentum, eps, coef};
+  return rn_sums_tail<2, true>(part, R, C, ws, tail, s);
 }
 
 int launch_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
@@ -779,22 +905,22 @@ int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, 
   float *kc = (float *)(part2 + (size_t)64 * 3 * C);
   const size_t lds = (size_t)256 * 8 * NS * 4;
   if (C / 8 > 256) return CRW_EINVAL;
-  int R2;
-  if (ext_part) {  // the sums came out of the epilogue of the product that made g (resnet_gemm.hip): only the merge is left
-    R2 = rn_rows_reduce(ext_part, ext_rows, NS * C, part2, s);
-  } else {
+  const float *sums = ext_part;  // the sums came out of the epilogue of the product that made g (resnet_gemm.hip): only the merge is left
+  int srows = ext_rows;
+  if (!ext_part) {
     if (NS == 3)
       hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<3>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
     else
       hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel<2>, dim3(nblk), dim3(256), lds, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, rows, rpb, C, part);
-    R2 = rn_rows_reduce(part, nblk, NS * C, part2, s);
+    sums = part;
+    srows = nblk;
   }
-  if (NS == 3)
-    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<3>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
-                       dgamma_d, dbeta_d, kc);
-  else
-    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<2>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
-                       dgamma_d, dbeta_d, kc);
+  {
+    const BwdTail<3> t3{(double)rows, dgamma, dbeta, dgamma_d, dbeta_d, kc};
+    const BwdTail<2> t2{(double)rows, dgamma, dbeta, dgamma_d, dbeta_d, kc};
+    const int st = NS == 3 ? rn_sums_tail<3, false>(sums, srows, C, part2, t3, s) : rn_sums_tail<2, false>(sums, srows, C, part2, t2, s);
+    if (st != CRW_OK) return st;
+  }
   const long real = rows * C / 8, total = (long)Ppad * npix * C / 8;
   hipLaunchKernelGGL(rn_bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, g1, g2, mask_hi, Z, coef, Zd, coef_d, kc, real, total,
                      C, dz_hi, dz_lo, dzd_hi, dzd_lo, g_out);
@@ -815,9 +941,11 @@ int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, co
   float *kc = (float *)(part2 + (size_t)64 * 3 * C);
   hipLaunchKernelGGL(rn_pool_bwd_reduce_kernel, dim3(nblk), dim3(256), (size_t)256 * 8 * 2 * 4, s, d1, d2, amax, Z, coef, rows, rpb, H, W, C,
                      part);
-  const int R2 = rn_rows_reduce(part, nblk, 2 * C, part2, s);
-  hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel<2>, dim3((C + 63) / 64), dim3(256), 0, s, part2, R2, C, (double)rows, dgamma, dbeta,
-                     (float *)nullptr, (float *)nullptr, kc);
+  {
+    const BwdTail<2> t2{(double)rows, dgamma, dbeta, nullptr, nullptr, kc};
+    const int st = rn_sums_tail<2, false>(part, nblk, C, part2, t2, s);
+    if (st != CRW_OK) return st;
+  }
   const long real = rows * C / 8, total = (long)Ppad * H * W * C / 8;
   hipLaunchKernelGGL(rn_pool_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, d1, d2, amax, Z, coef, kc, real, total, H, W, C, dz_hi,
                      dz_lo);
