@@ -155,19 +155,19 @@ def resnet_event_kernels(ev, P, steps):
             _, _, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad = key
             if mode == crw_hip.RN_FWD:
                 alg, ex = 2.0 * P * _rn_pairs(Hs, Ws, Hd, Wd, k, stride, pad) * Cs * N, 1.0
-                name = f"rn_conv_kernel fwd {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
+                name = f"rn_conv_spec_kernel fwd {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
             elif mode == crw_hip.RN_BWD:
                 alg, ex = 2.0 * P * _rn_pairs(Hd, Wd, Hs, Ws, k, stride, pad) * Cs * N, 1.0
-                name = f"rn_conv_kernel bwd-data {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
+                name = f"rn_conv_spec_kernel bwd-data (+ BatchNorm-backward sums) {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
             elif mode == crw_hip.RN_STEM_FWD:
                 alg, ex = 2.0 * P * Hd * Wd * 147 * 64, 256.0 / 147.0   # K = 8 kernel rows x 32 for the 7 x 7 x 3 = 147 taps
-                name = "rn_conv_kernel stem fwd 7x7/2 3 -> 64"
+                name = "rn_stem_fwd_kernel 7x7/2 3 -> 64 (patch per wave; rn_conv_spec_kernel at other patch sizes)"
             else:
                 alg = 2.0 * P * 81 * 147 * 64
                 # executed: 18 map rows x 64 columns x the dZ rows each one sees (Toeplitz planes: zeros are multiplied)
                 rows = sum(min(8, (iy + 3) // 2) - max(0, (iy - 2) // 2 if iy > 3 else 0) + 1 for iy in range(Hd))
                 ex = (2.0 * P * 64 * rows * 9 * 64) / alg
-                name = "rn_conv_kernel stem bwd-data (Toeplitz) 64 -> 3"
+                name = "rn_stem_bwd_kernel 64 -> 3 (patch per wave; rn_conv_kernel on Toeplitz planes at other patch sizes)"
         else:
             _, _, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad = key
             if mode == crw_hip.RN_FWD:
@@ -175,7 +175,7 @@ def resnet_event_kernels(ev, P, steps):
                 name = f"rn_wgrad_kernel {Hin}x{Win}x{Cin} -> {Hout}x{Wout}x{Cout} k{k}/s{stride} (+ slab sum)"
             else:
                 alg, ex = 2.0 * P * Hout * Wout * 147 * 64, 256.0 / 147.0
-                name = "rn_wgrad_kernel stem 7x7/2 (+ slab sum)"
+                name = "rn_stem_wgrad_kernel 7x7/2 (+ slab sum) (patch per wave pair; rn_wgrad_kernel at other patch sizes)"
         kms = sum(pairs) / len(pairs)  # ms of every timed launch (crw_rn_timing_read)
         out.append({"kernel": name, "bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
                     "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],

@@ -85,15 +85,18 @@ __device__ inline int xcd_linear(int bid, int total) {
 // =============================================================================================== NN: conv forward / backward-data
 constexpr int RN_MAXSEG = 64;
 
-template <int TN, int BK, int NSTAGE>
+template <int TN, int BK, int NSTAGE, int TM_ = 128>
 struct NNCfg {
-  static constexpr int TM = 128, WAVES = 4, FM = 4, FN = TN / 32;
+  // TM x TN tile, one wave per 64 x TN/2 sub-tile: 4 waves (2 x 2) at 128 rows, 8 waves (4 x 2) at 256
+  static constexpr int TM = TM_, WAVES = TM / 32, FM = 4, FN = TN / 32;
   static constexpr int IMG_A = TM * 2 * BK, IMG_B = TN * 2 * BK, STAGE = 2 * IMG_A + 2 * IMG_B;
-  static constexpr int PA = TM * BK / 512 / WAVES, PB = TN * BK / 512 / WAVES;  // 1 KiB pieces per wave and image
-  static constexpr int G = 2 * PA + 2 * PB;                                     // LDS-DMA instructions per wave and k-tile
+  static constexpr int PIECES_A = TM * BK / 512, PIECES_B = TN * BK / 512;        // 1 KiB pieces per image
+  static constexpr int PA = PIECES_A / WAVES, PB = (PIECES_B + WAVES - 1) / WAVES;  // per wave (the last B round may be partial)
+  static constexpr int G = 2 * PA + 2 * PB;                                      // LDS-DMA instructions per wave and k-tile
   static constexpr int TABLE = 2 * RN_MAXSEG * 4 + 16;
   static constexpr size_t LDS = (size_t)NSTAGE * STAGE + TABLE;
-  static_assert(PA >= 1 && PB >= 1, "pieces per wave");
+  static_assert(PA >= 1 && PIECES_A % WAVES == 0, "A pieces per wave");
+  static_assert(PIECES_B % WAVES == 0 || NSTAGE == 2, "a partial B round needs the uncounted vmcnt(0) of the two-stage ring");
 };
 
 // the segments of group g: seg_a[] = element offset of the segment inside an A row, seg_b[] = inside a B row
@@ -150,12 +153,115 @@ __device__ inline void rn_segments(const RnConvArgs &a, int g, int lane, int *se
   }
 }
 
+// LDS the EPI = 2 epilogue needs: the fp32 tile with TN + 4 floats per row, then the per-thread column sums [TM/64][3][row lanes][TN]
+template <int TN, int TM, int NT = TM * 2>
+constexpr size_t rn_epi2_lds() {
+  const size_t tile = (size_t)TM * (TN + 4) * 4, sums = (size_t)(TM / 64) * 3 * (NT / (TN / 4)) * TN * 4;
+  return tile > sums ? tile : sums;
+}
+
+
+// The EPI = 2 epilogue: the tile goes through LDS (the ring is free) and comes back row-contiguous for NT threads -- the waves that
+// hold accumulators (has_acc) write them, every wave of the workgroup takes part in the row pass.
+template <int TN, int TM, int NT, int FM, int FN>
+__device__ inline void rn_epi2_staged(const RnConvArgs &a, char *lds, const f32x4 (&acc)[FM][FN], bool has_acc, int wm, int wn, int lane,
+                                      int m0, int n0, int g, int mt) {
+  // The tile goes through LDS (the ring is free now) and comes back row-contiguous: float4 stores of whole 128-byte lines and
+  // float4 / 8-byte loads of the consuming layer's Z and activation planes.  (Straight from the MFMA layout -- 4-byte
+  // accesses, 16 lanes per row segment -- the extra loads cost as much as the separate reduce pass they replace.)
+  constexpr int LDT = TN + 4;                   // row stride in floats: the four row groups of a wave hit disjoint banks
+  constexpr int TPR = TN / 4, RPP = NT / TPR;   // threads per row (one float4 each), rows per pass
+  constexpr int NH = TM / 64;                   // 64-row pieces of the tile: one partial row of sums each
+  constexpr int NB = NT == 512 ? 2 : ((64 / RPP) % 4 == 0 ? 4 : 64 / RPP);  // passes whose loads are in flight together (512 threads: 128-register budget)
+  static_assert(64 % RPP == 0 && (64 / RPP) % NB == 0, "passes per 64-row piece");
+  float *tile = reinterpret_cast<float *>(lds);
+  const int nsum = a.red_zd ? 3 : 2;
+  __syncthreads();  // every wave has read its last fragments
+  if (has_acc) {
+    const int gq = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(wm + 16 * i + 4 * gq + r) * LDT + wn + 16 * j + c16] = acc[i][j][r];
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+  const int col = n0 + 4 * c4;
+  const float4 mean = *reinterpret_cast<const float4 *>(a.red_coef + 2 * a.N + col);
+  const float4 istd = *reinterpret_cast<const float4 *>(a.red_coef + 3 * a.N + col);
+  float4 mean_d = float4{0.f, 0.f, 0.f, 0.f}, istd_d = mean_d;
+  if (a.red_zd) {
+    mean_d = *reinterpret_cast<const float4 *>(a.red_coefd + 2 * a.N + col);
+    istd_d = *reinterpret_cast<const float4 *>(a.red_coefd + 3 * a.N + col);
+  }
+  const long base = (long)m0 * a.ldc + (long)g * a.N + col;
+  float sums[NH][3][4];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sums[h][k][e] = 0.f;
+#pragma unroll 1
+    for (int p0 = 0; p0 < 64 / RPP; p0 += NB) {
+      float4 prev[NB], z[NB], zd[NB];
+      uint2 mk[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const long idx = base + (long)(64 * h + (p0 + u) * RPP + rl) * a.ldc;
+        prev[u] = a.accumulate ? *reinterpret_cast<const float4 *>(a.out + idx) : float4{0.f, 0.f, 0.f, 0.f};
+        mk[u] = *reinterpret_cast<const uint2 *>(a.red_mask + idx);
+        z[u] = *reinterpret_cast<const float4 *>(a.red_z + idx);
+        zd[u] = a.red_zd ? *reinterpret_cast<const float4 *>(a.red_zd + idx) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int row = 64 * h + (p0 + u) * RPP + rl;
+        float4 v = *reinterpret_cast<const float4 *>(tile + row * LDT + 4 * c4);
+        v.x += prev[u].x; v.y += prev[u].y; v.z += prev[u].z; v.w += prev[u].w;
+        *reinterpret_cast<float4 *>(a.out + base + (long)row * a.ldc) = v;
+        const float gv[4] = {(mk[u].x & 0xffffu) ? v.x : 0.f, (mk[u].x >> 16) ? v.y : 0.f, (mk[u].y & 0xffffu) ? v.z : 0.f,
+                             (mk[u].y >> 16) ? v.w : 0.f};
+        const float zz[4] = {z[u].x, z[u].y, z[u].z, z[u].w}, zzd[4] = {zd[u].x, zd[u].y, zd[u].z, zd[u].w};
+        const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, ii[4] = {istd.x, istd.y, istd.z, istd.w};
+        const float mmd[4] = {mean_d.x, mean_d.y, mean_d.z, mean_d.w}, iid[4] = {istd_d.x, istd_d.y, istd_d.z, istd_d.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sums[h][0][e] += gv[e];
+          sums[h][1][e] += gv[e] * ((zz[e] - mm[e]) * ii[e]);
+          sums[h][2][e] += gv[e] * ((zzd[e] - mmd[e]) * iid[e]);
+        }
+      }
+    }
+  }
+  __syncthreads();  // the tile has been read
+  float *red = tile;  // [NH pieces][3 sums][RPP row lanes][TN]
+  static_assert(rn_epi2_lds<TN, TM, NT>() >= (size_t)NH * 3 * RPP * TN * 4 && rn_epi2_lds<TN, TM, NT>() >= (size_t)TM * LDT * 4, "staging space");
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      *reinterpret_cast<float4 *>(red + ((h * 3 + k) * RPP + rl) * TN + 4 * c4) =
+          float4{sums[h][k][0], sums[h][k][1], sums[h][k][2], sums[h][k][3]};
+  __syncthreads();
+  for (int o = threadIdx.x; o < NH * nsum * TN; o += NT) {  // [row][nsum][N]: the layout of rn_bn_bwd_reduce_kernel's partials
+    const int c = o % TN, k = (o / TN) % nsum, h = o / (TN * nsum);
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPP; ++q) t += red[((h * 3 + k) * RPP + q) * TN + c];
+    a.red_part[(((long)(mt * NH + h) * a.G + g) * nsum + k) * a.N + n0 + c] = t;
+  }
+}
+
 // EPI: what the epilogue does besides storing the fp32 tile -- 0: (+ bias) and the forward statistics partials; 1: adds the tile to
 // what `out` holds (second gradient of a junction); 2: that (optionally) plus the BatchNorm-backward sums of the consuming layer.
 // Separate kernels: as run-time variants of one kernel they cost every launch its second workgroup per CU (104 -> 256 registers).
-template <int TN, int BK, int NSTAGE, int EPI>
-__global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two workgroups per CU (short k-loops: they cover each other)
-  using C = NNCfg<TN, BK, NSTAGE>;
+template <int TN, int BK, int NSTAGE, int EPI, int TM = 128>
+__global__ __launch_bounds__(TM * 2) void rn_conv_kernel(RnConvArgs a) {  // TM = 128: two workgroups per CU (short k-loops: they cover each other)
+  using C = NNCfg<TN, BK, NSTAGE, TM>;
+  constexpr int NT = TM * 2;  // threads
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int *seg_a = reinterpret_cast<int *>(lds + NSTAGE * C::STAGE);
   int *seg_b = seg_a + RN_MAXSEG;
@@ -196,9 +302,11 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two wo
 #pragma unroll
     for (int i = 0; i < C::PB; ++i) {
       const int piece = C::WAVES * i + wave;
-      const long off = b_row0 + (long)(RPP * piece) * a.ldb + bcol;
-      glds16(Bh + off, base + 2 * C::IMG_A + piece * 1024);
-      glds16(Bl + off, base + 2 * C::IMG_A + C::IMG_B + piece * 1024);
+      if (C::PIECES_B % C::WAVES == 0 || piece < C::PIECES_B) {
+        const long off = b_row0 + (long)(RPP * piece) * a.ldb + bcol;
+        glds16(Bh + off, base + 2 * C::IMG_A + piece * 1024);
+        glds16(Bl + off, base + 2 * C::IMG_A + C::IMG_B + piece * 1024);
+      }
     }
   };
 
@@ -248,98 +356,14 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two wo
   // Three straight-line variants under wave-uniform tests (conditions inside the store loops made every variant wait for each
   // element's load before its store: +35 % on all launches).
   const long crow0 = (long)(m0 + wm + (lane >> 4) * 4) * a.ldc + (long)g * a.N + n0 + wn + (lane & 15);
-  const long prow = (long)(mt * 2 + (wave >> 1)) * a.G + g;
+  const long prow = (long)(mt * (TM / 64) + (wave >> 1)) * a.G + g;
   auto colsum = [&](float v) {  // over the wave's 64 rows: lanes 0..15 end up with the column totals
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;
   };
   if constexpr (EPI == 2) {
-    // The tile goes through LDS (the ring is free now) and comes back row-contiguous: float4 stores of whole 128-byte lines and
-    // float4 / 8-byte loads of the consuming layer's Z and activation planes.  (Straight from the MFMA layout -- 4-byte
-    // accesses, 16 lanes per row segment -- the extra loads cost as much as the separate reduce pass they replace.)
-    constexpr int LDT = TN + 4;                   // row stride in floats: the four row groups of a wave hit disjoint banks
-    constexpr int TPR = TN / 4, RPP = 256 / TPR;  // threads per row (one float4 each), rows per pass
-    constexpr int NB = 4;                         // passes whose loads are in flight together
-    static_assert((64 / RPP) % NB == 0, "passes per half tile");
-    float *tile = reinterpret_cast<float *>(lds);
-    const int nsum = a.red_zd ? 3 : 2;
-    __syncthreads();  // every wave has read its last fragments
-    {
-      const int gq = lane >> 4, c16 = lane & 15;
-#pragma unroll
-      for (int i = 0; i < C::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::FN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tile[(wm + 16 * i + 4 * gq + r) * LDT + wn + 16 * j + c16] = acc[i][j][r];
-    }
-    __syncthreads();
-    const int c4 = threadIdx.x % TPR, rl = threadIdx.x / TPR;
-    const int col = n0 + 4 * c4;
-    const float4 mean = *reinterpret_cast<const float4 *>(a.red_coef + 2 * a.N + col);
-    const float4 istd = *reinterpret_cast<const float4 *>(a.red_coef + 3 * a.N + col);
-    float4 mean_d = float4{0.f, 0.f, 0.f, 0.f}, istd_d = mean_d;
-    if (a.red_zd) {
-      mean_d = *reinterpret_cast<const float4 *>(a.red_coefd + 2 * a.N + col);
-      istd_d = *reinterpret_cast<const float4 *>(a.red_coefd + 3 * a.N + col);
-    }
-    const long base = (long)m0 * a.ldc + (long)g * a.N + col;
-    float sums[2][3][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sums[h][k][e] = 0.f;
-#pragma unroll 1
-      for (int p0 = 0; p0 < 64 / RPP; p0 += NB) {
-        float4 prev[NB], z[NB], zd[NB];
-        uint2 mk[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const long idx = base + (long)(64 * h + (p0 + u) * RPP + rl) * a.ldc;
-          prev[u] = a.accumulate ? *reinterpret_cast<const float4 *>(a.out + idx) : float4{0.f, 0.f, 0.f, 0.f};
-          mk[u] = *reinterpret_cast<const uint2 *>(a.red_mask + idx);
-          z[u] = *reinterpret_cast<const float4 *>(a.red_z + idx);
-          zd[u] = a.red_zd ? *reinterpret_cast<const float4 *>(a.red_zd + idx) : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int row = 64 * h + (p0 + u) * RPP + rl;
-          float4 v = *reinterpret_cast<const float4 *>(tile + row * LDT + 4 * c4);
-          v.x += prev[u].x; v.y += prev[u].y; v.z += prev[u].z; v.w += prev[u].w;
-          *reinterpret_cast<float4 *>(a.out + base + (long)row * a.ldc) = v;
-          const float gv[4] = {(mk[u].x & 0xffffu) ? v.x : 0.f, (mk[u].x >> 16) ? v.y : 0.f, (mk[u].y & 0xffffu) ? v.z : 0.f,
-                               (mk[u].y >> 16) ? v.w : 0.f};
-          const float zz[4] = {z[u].x, z[u].y, z[u].z, z[u].w}, zzd[4] = {zd[u].x, zd[u].y, zd[u].z, zd[u].w};
-          const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, ii[4] = {istd.x, istd.y, istd.z, istd.w};
-          const float mmd[4] = {mean_d.x, mean_d.y, mean_d.z, mean_d.w}, iid[4] = {istd_d.x, istd_d.y, istd_d.z, istd_d.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            sums[h][0][e] += gv[e];
-            sums[h][1][e] += gv[e] * ((zz[e] - mm[e]) * ii[e]);
-            sums[h][2][e] += gv[e] * ((zzd[e] - mmd[e]) * iid[e]);
-          }
-        }
-      }
-    }
-    __syncthreads();  // the tile has been read
-    float *red = tile;  // [2 halves][3 sums][RPP row lanes][TN]
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        *reinterpret_cast<float4 *>(red + ((h * 3 + k) * RPP + rl) * TN + 4 * c4) =
-            float4{sums[h][k][0], sums[h][k][1], sums[h][k][2], sums[h][k][3]};
-    __syncthreads();
-    for (int o = threadIdx.x; o < 2 * nsum * TN; o += 256) {  // [row][nsum][N]: the layout of rn_bn_bwd_reduce_kernel's partials
-      const int c = o % TN, k = (o / TN) % nsum, h = o / (TN * nsum);
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < RPP; ++q) t += red[((h * 3 + k) * RPP + q) * TN + c];
-      a.red_part[(((long)(mt * 2 + h) * a.G + g) * nsum + k) * a.N + n0 + c] = t;
-    }
+    rn_epi2_staged<TN, TM, NT, C::FM, C::FN>(a, lds, acc, true, wm, wn, lane, m0, n0, g, mt);
   } else if constexpr (EPI == 1) {
 #pragma unroll
     for (int j = 0; j < C::FN; ++j) {
@@ -377,14 +401,181 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {  // two wo
   }
 }
 
-template <int TN, int BK, int NSTAGE, int EPI>
+template <int TN, int BK, int NSTAGE, int EPI, int TM = 128>
 int launch_conv_epi(const RnConvArgs &a, hipStream_t s) {
-  using C = NNCfg<TN, BK, NSTAGE>;
-  constexpr size_t staged = (size_t)C::TM * (TN + 4) * 4;  // EPI 2 passes the output tile through LDS
+  using C = NNCfg<TN, BK, NSTAGE, TM>;
+  constexpr size_t staged = rn_epi2_lds<TN, TM>();  // EPI 2 passes the output tile through LDS
   constexpr size_t lds_bytes = (EPI == 2 && staged > C::LDS) ? staged : C::LDS;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)rn_conv_kernel<TN, BK, NSTAGE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)rn_conv_kernel<TN, BK, NSTAGE, EPI, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr_set = true;
+  }
+  const int total = a.mtiles / (TM / 128) * (a.N / TN) * a.G;
+  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE, EPI, TM>), dim3(total), dim3(TM * 2), lds_bytes, s, a);
+  return check_launch();
+}
+
+// ---- the same product with the roles split over the waves of a 512-thread workgroup ----------------------------------------------
+// Waves 0-3 run the MFMAs (the 2 x 2 layout of rn_conv_kernel), waves 4-7 only issue the LDS-DMA of the ring, NSTAGE-1 k-tiles
+// ahead.  An LDS-DMA piece costs its wave 60-180 issue cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): 8 pieces per
+// k-tile are as long as the k-tile's 48 MFMAs, and in rn_conv_kernel every wave pays both in turn.  One barrier per k-tile as
+// before: the loaders arrive when tile t has landed, the consumers when they have read tile t-1.
+template <int TN, int BK, int NSTAGE, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void rn_conv_spec_kernel(RnConvArgs a) {  // two workgroups per CU
+  using C = NNCfg<TN, BK, NSTAGE>;
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int *seg_a = reinterpret_cast<int *>(lds + NSTAGE * C::STAGE);
+  int *seg_b = seg_a + RN_MAXSEG;
+  int *hdr = seg_b + RN_MAXSEG;
+  const int lane = threadIdx.x & 63, wave8 = threadIdx.x >> 6;
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int ntiles = a.N / TN;
+  const int lin = xcd_linear(blockIdx.x, gridDim.x);
+  const int per_mt = ntiles * a.G;
+  const int mt = lin / per_mt, rest = lin % per_mt;
+  const int g = rest / ntiles, nt = rest % ntiles;
+  const int m0 = mt * C::TM, n0 = nt * TN;
+
+  if (wave8 == 0) rn_segments(a, g, lane, seg_a, seg_b, hdr);
+  __syncthreads();
+  const int K = hdr[1], shift = hdr[2];
+  const int nkt = K / BK;
+
+  if (loader) {
+    const unsigned kmask = (1u << shift) - 1u;
+    const uint16_t *Bh = a.b_hi + (long)g * a.b_group_stride, *Bl = a.b_lo + (long)g * a.b_group_stride;
+    constexpr int LPR = BK / 8, RPP = 64 / LPR;
+    const int lrow = lane / LPR;
+    const int gchunk = (lane % LPR) ^ kc_sw<BK>(lrow);
+    const long a_row0 = (long)(m0 + lrow) * a.lda, b_row0 = (long)(n0 + lrow) * a.ldb;
+    auto stage = [&](int t, int buf) {
+      char *base = lds + buf * C::STAGE;
+      const unsigned k = (unsigned)(t * BK + 8 * gchunk);
+      const int sg = (int)(k >> shift), within = (int)(k & kmask);
+      const int acol = seg_a[sg] + within, bcol = seg_b[sg] + within;
+#pragma unroll
+      for (int i = 0; i < C::PA; ++i) {
+        const int piece = C::WAVES * i + wave;
+        const long off = a_row0 + (long)(RPP * piece) * a.lda + acol;
+        glds16(a.a_hi + off, base + piece * 1024);
+        glds16(a.a_lo + off, base + C::IMG_A + piece * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < C::PB; ++i) {
+        const int piece = C::WAVES * i + wave;
+        const long off = b_row0 + (long)(RPP * piece) * a.ldb + bcol;
+        glds16(Bh + off, base + 2 * C::IMG_A + piece * 1024);
+        glds16(Bl + off, base + 2 * C::IMG_A + C::IMG_B + piece * 1024);
+      }
+    };
+    for (int t = 0; t < NSTAGE - 1 && t < nkt; ++t) stage(t, t);
+    for (int t = 0; t < nkt; ++t) {
+      const int ahead = min(NSTAGE - 2, nkt - 1 - t);  // k-tiles issued after tile t
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::G) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile t has landed; the consumers have left the buffer of tile t-1
+      if (t + NSTAGE - 1 < nkt) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+    }
+    if constexpr (EPI == 2) {  // the loaders take their share of the row pass
+      f32x4 none[C::FM][C::FN];
+      rn_epi2_staged<TN, C::TM, 512, C::FM, C::FN>(a, lds, none, false, 0, 0, lane, m0, n0, g, mt);
+    }
+    return;
+  }
+
+  f32x4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (TN / 2);
+  for (int t = 0; t < nkt; ++t) {
+    __builtin_amdgcn_s_barrier();
+    const char *base = lds + (t % NSTAGE) * C::STAGE;
+#pragma unroll
+    for (int s = 0; s < BK / 32; ++s) {
+      bf8 b[C::FN], bl[C::FN], af[C::FM], al[C::FM];
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        b[j] = kc_frag<BK>(base + 2 * C::IMG_A, wn + 16 * j, s, lane);
+        bl[j] = kc_frag<BK>(base + 2 * C::IMG_A + C::IMG_B, wn + 16 * j, s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i) {
+        af[i] = kc_frag<BK>(base, wm + 16 * i, s, lane);
+        al[i] = kc_frag<BK>(base + C::IMG_A, wm + 16 * i, s, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) {
+          acc[i][j] = mfma(al[i], b[j], acc[i][j]);
+          acc[i][j] = mfma(af[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma(af[i], b[j], acc[i][j]);
+        }
+    }
+  }
+  if constexpr (EPI == 2) {
+    rn_epi2_staged<TN, C::TM, 512, C::FM, C::FN>(a, lds, acc, true, wm, wn, lane, m0, n0, g, mt);
+    return;
+  }
+  const long crow0 = (long)(m0 + wm + (lane >> 4) * 4) * a.ldc + (long)g * a.N + n0 + wn + (lane & 15);
+  const long prow = (long)(mt * 2 + (wave >> 1)) * a.G + g;
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) {
+      float prev[C::FM][4];
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prev[i][r] = a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j];
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j] = acc[i][j][r] + prev[i][r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < C::FN; ++j) {
+    const int col = n0 + wn + 16 * j + (lane & 15);
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[i][j][r] + bias;
+        a.out[crow0 + (long)(16 * i + r) * a.ldc + 16 * j] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    if (a.part) {
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 16) reinterpret_cast<float2 *>(a.part)[prow * a.N + col] = float2{s1, s2};
+    }
+  }
+}
+
+template <int TN, int BK, int NSTAGE, int EPI>
+int launch_conv_spec_epi(const RnConvArgs &a, hipStream_t s) {
+  using C = NNCfg<TN, BK, NSTAGE>;
+  constexpr size_t staged = rn_epi2_lds<TN, C::TM, 512>();
+  constexpr size_t lds_bytes = (EPI == 2 && staged > C::LDS) ? staged : C::LDS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)rn_conv_spec_kernel<TN, BK, NSTAGE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
@@ -392,15 +583,22 @@ int launch_conv_epi(const RnConvArgs &a, hipStream_t s) {
     attr_set = true;
   }
   const int total = a.mtiles * (a.N / TN) * a.G;
-  hipLaunchKernelGGL((rn_conv_kernel<TN, BK, NSTAGE, EPI>), dim3(total), dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL((rn_conv_spec_kernel<TN, BK, NSTAGE, EPI>), dim3(total), dim3(512), lds_bytes, s, a);
   return check_launch();
 }
 
 template <int TN, int BK, int NSTAGE>
+int launch_conv_spec(const RnConvArgs &a, hipStream_t s) {
+  if (a.red_mask) return launch_conv_spec_epi<TN, BK, NSTAGE, 2>(a, s);
+  if (a.accumulate) return launch_conv_spec_epi<TN, BK, NSTAGE, 1>(a, s);
+  return launch_conv_spec_epi<TN, BK, NSTAGE, 0>(a, s);
+}
+
+template <int TN, int BK, int NSTAGE, int TM = 128>
 int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
-  if (a.red_mask) return launch_conv_epi<TN, BK, NSTAGE, 2>(a, s);
-  if (a.accumulate) return launch_conv_epi<TN, BK, NSTAGE, 1>(a, s);
-  return launch_conv_epi<TN, BK, NSTAGE, 0>(a, s);
+  if (a.red_mask) return launch_conv_epi<TN, BK, NSTAGE, 2, TM>(a, s);
+  if (a.accumulate) return launch_conv_epi<TN, BK, NSTAGE, 1, TM>(a, s);
+  return launch_conv_epi<TN, BK, NSTAGE, 0, TM>(a, s);
 }
 
 // =============================================================================================== TN: weight gradients
@@ -621,6 +819,16 @@ int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
   // covers the first one's prologue / epilogue: 32-deep k-tiles -- three stages for the 64-column tiles (72 KB of LDS; layer1 and
   // the stem forward 20 % faster than on two 64-deep stages), two stages for the 128-column tiles (64 KB; step 6.9 -> 6.6 ms);
   // the long single segment of the stem's backward-data product prefers two 64-deep stages.  CRW_RN_BK = 64 | 32 | 322 forces one.
+  // Default: the split-role kernel (4 MFMA waves + 4 LDS-DMA waves, two 512-thread workgroups per CU, two 32-deep stages): the step
+  // measured 1.1-1.4 % faster than on rn_conv_kernel's 4-wave workgroups (4.75 -> 4.69 ms); deeper rings (one workgroup per CU) and
+  // 256-patch tiles on 8 waves (rn_conv_kernel<..., TM = 256>: a quarter fewer staged bytes per flop, but one workgroup per CU)
+  // measured no faster: 4.77 / 4.82 / 4.74 ms.  CRW_RN_SPEC=0 selects rn_conv_kernel, =3 / =4 the deeper rings.
+  static const int spec = [] { const char *e = getenv("CRW_RN_SPEC"); return e ? atoi(e) : 2; }();
+  if (spec && a.mode != RN_MODE_STEM_BWD) {
+    if (spec == 3) return wide ? launch_conv_spec<128, 32, 3>(a, s) : launch_conv_spec<64, 32, 3>(a, s);
+    if (spec == 4) return wide ? launch_conv_spec<128, 32, 4>(a, s) : launch_conv_spec<64, 32, 4>(a, s);
+    return wide ? launch_conv_spec<128, 32, 2>(a, s) : launch_conv_spec<64, 32, 2>(a, s);
+  }
   int bk = rn_conv_bk();
   if (bk != 32 && bk != 64 && bk != 322) bk = a.mode == RN_MODE_STEM_BWD ? 64 : 322;
   if (bk == 322) return wide ? launch_conv_cfg<128, 32, 2>(a, s) : launch_conv_cfg<64, 32, 3>(a, s);
