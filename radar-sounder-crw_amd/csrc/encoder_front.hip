@@ -1,8 +1,10 @@
 // Fused front end of the CNN encoder (src/encoder.py:13-24,46-47):
 //     x [cin,16,16] -> conv1 5x5 pad 1 (cin->8) -> ReLU -> maxpool 2x2/1 -> conv2 5x5 pad 1 (8->32)
 //       -> ReLU -> maxpool 2x2/1 -> [100][32] channels-last bf16 planes (hi[,lo]) for conv3.
-// One persistent workgroup (1024 threads = 16 waves) streams patches, the next patch prefetched into registers;
-// everything between the 1 KB input patch and the 6.4 KB output planes stays in LDS.
+// Persistent workgroups stream patches, the next patch prefetched into registers; everything between the 1 KB input patch
+// and the 6.4 KB output planes stays in LDS.  Forward: two 512-thread workgroups per CU (60 KB of LDS each) that fill each
+// other's barrier waits (0.27 -> 0.21 ms per 16128 patches against one 1024-thread workgroup); backward: one 1024-thread
+// workgroup per CU (98 KB of LDS).
 //   conv1 (25*cin MACs per output, 3 % of this stage): fp32 VALU, exact.
 //   conv2 (200 MACs per output): implicit GEMM on v_mfma_f32_16x16x32_bf16 with k = (tap, ci): one
 //     32-deep k-step = 4 taps x 8 input channels, so an A fragment is ONE 16-byte channels-last read
@@ -111,10 +113,10 @@ __device__ inline void conv1_relu(const FwdLds &L, int cin, int tid) {
 
 // maxpool 2x2/1 of c1r -> a1 planes (interior of the 15x15 padded image)
 __device__ inline int argmax4(float a, float b, float c, float d);
-template <int SPLIT, bool PAD>
+template <int SPLIT, bool PAD, int NT = NTH>
 __device__ inline void pool1(const FwdLds &L, int tid, char *sv = nullptr) {  // sv: this patch's saved record (or null)
   constexpr int ROW = (PAD ? C1W + 2 : C1W) * 8;
-  for (int e = tid; e < A1W * A1W * 8; e += NTH) {
+  for (int e = tid; e < A1W * A1W * 8; e += NT) {
     const int c = e & 7, p = e >> 3, y = p / A1W, x = p % A1W;
     const float *s = L.c1r + c1_idx<PAD>(y, x) * 8 + c;
     const float v = fmaxf(fmaxf(s[0], s[8]), fmaxf(s[ROW], s[ROW + 8]));
@@ -138,15 +140,24 @@ __device__ inline int w2_lds_chunk(int e) {  // 16-byte chunk index: global -> L
   return ((s * 2 + (ch >> 1)) * 32 + co) * 2 + (ch & 1);
 }
 
-// conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  16 output tiles (8 row x 2 column), one per wave.
-template <int SPLIT, bool PAD>
+// conv2 + bias + ReLU on the matrix cores -> c2r [121][32] fp32.  16 output tiles (8 row x 2 column): one per wave of a
+// 1024-thread workgroup; a 512-thread workgroup gives each wave two row tiles of the same column tile, so the weight
+// fragments are read once for both (6 LDS reads per 6 MFMAs instead of 8).
+template <int SPLIT, bool PAD, int NT = NTH>
 __device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bias = b2[16 (wave & 1) + lane % 16]
+  constexpr int NW = NT / 64, U = 16 / NW;
+  static_assert(NW % 2 == 0 && 16 % NW == 0, "waves per workgroup");
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
-  const int mt = wave >> 1, j = wave & 1;
-  int i0 = 16 * mt + r16;
-  if (i0 >= C2N) i0 = 0;
-  const int base = (i0 / C2W) * A1PW + (i0 % C2W);  // padded a1 pixel of tap (0,0)
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int j = wave & 1;
+  int base[U];  // padded a1 pixel of tap (0,0)
+  f32x4 acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int i0 = 16 * ((wave + NW * u) >> 1) + r16;
+    if (i0 >= C2N) i0 = 0;
+    base[u] = (i0 / C2W) * A1PW + (i0 % C2W);
+    acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int s = 0; s < KS2; ++s) {
     int tap = 4 * s + g;
@@ -154,22 +165,28 @@ __device__ inline void conv2_relu(const FwdLds &L, float bias, int tid) {  // bi
     const int toff = (tap / 5) * A1PW + (tap % 5);
     const int o = (((s * 2 + (g >> 1)) * 32 + 16 * j + r16) * 2 + (g & 1)) * 16;
     const bf8 bh = *reinterpret_cast<const bf8 *>(L.w2h + o);
-    const bf8 ah = *reinterpret_cast<const bf8 *>(L.a1h + (base + toff) * 16);
-    if (SPLIT == 3) {
-      const bf8 bl = *reinterpret_cast<const bf8 *>(L.w2l + o);
-      const bf8 al = *reinterpret_cast<const bf8 *>(L.a1l + (base + toff) * 16);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    bf8 bl;
+    if (SPLIT == 3) bl = *reinterpret_cast<const bf8 *>(L.w2l + o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bf8 ah = *reinterpret_cast<const bf8 *>(L.a1h + (base[u] + toff) * 16);
+      if (SPLIT == 3) {
+        const bf8 al = *reinterpret_cast<const bf8 *>(L.a1l + (base[u] + toff) * 16);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[u], 0, 0, 0);
+      }
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[u], 0, 0, 0);
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
   }
   const int co = 16 * j + r16;
   const float b = bias;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 16 * mt + 4 * g + r;
-    if (i < C2N) L.c2r[c2_idx<PAD>(i / C2W, i % C2W) * 32 + co] = fmaxf(acc[r] + b, 0.f);
-  }
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ((wave + NW * u) >> 1) + 4 * g + r;
+      if (i < C2N) L.c2r[c2_idx<PAD>(i / C2W, i % C2W) * 32 + co] = fmaxf(acc[u][r] + b, 0.f);
+    }
 }
 
 __device__ inline FwdLds carve_fwd(char *&p, int cin, bool pad = false) {  // pad: bordered c1r / c2r (backward kernel)
@@ -186,32 +203,34 @@ __device__ inline FwdLds carve_fwd(char *&p, int cin, bool pad = false) {  // pa
   return L;
 }
 
-template <int SPLIT>
+template <int SPLIT, int NT = NTH>
 __device__ inline void stage_constants(const FwdLds &L, const FrontArgs &a, int tid) {
-  for (int e = tid; e < a.cin * XPW * XPW; e += NTH) L.xs[e] = 0.f;  // zero border of the padded patch
-  for (int e = tid; e < 8 * a.cin * 25; e += NTH) {  // [co][ci][tap] -> [ci][tap][co]
+  for (int e = tid; e < a.cin * XPW * XPW; e += NT) L.xs[e] = 0.f;  // zero border of the padded patch
+  for (int e = tid; e < 8 * a.cin * 25; e += NT) {  // [co][ci][tap] -> [ci][tap][co]
     const int t = e % 25, ci = (e / 25) % a.cin, co = e / (25 * a.cin);
     L.w1[(ci * 25 + t) * 8 + co] = a.w1[e];
   }
   if (tid < 8) L.w1[8 * a.cin * 25 + tid] = a.b1[tid];
-  for (int e = tid; e < A1PW * A1PW * 4; e += NTH) {  // zero halo (and interior) of the a1 planes
+  for (int e = tid; e < A1PW * A1PW * 4; e += NT) {  // zero halo (and interior) of the a1 planes
     reinterpret_cast<uint32_t *>(L.a1h)[e] = 0;
     reinterpret_cast<uint32_t *>(L.a1l)[e] = 0;
   }
-  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
+  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NT) {
     const int d = w2_lds_chunk(e);
     reinterpret_cast<uint4 *>(L.w2h)[d] = reinterpret_cast<const uint4 *>(a.w2h)[e];
     if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[d] = reinterpret_cast<const uint4 *>(a.w2l)[e];
   }
 }
 
-template <int SPLIT>
-__global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
+// NT = 512: two workgroups share a CU (60 KB of LDS and <= 128 registers each) and fill each other's barrier waits; at 1024 threads
+// the 122 registers of the hi/lo instance admit one workgroup per CU only.
+template <int SPLIT, int NT>
+__global__ __launch_bounds__(NT) void front_fwd_kernel(FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char *p = lds;
   const FwdLds L = carve_fwd(p, a.cin);
   const int tid = threadIdx.x;
-  stage_constants<SPLIT>(L, a, tid);
+  stage_constants<SPLIT, NT>(L, a, tid);
   __syncthreads();
   const float b2r = a.b2[16 * ((tid >> 6) & 1) + (tid & 15)];  // read once: the barriers in the loop are memory clobbers
   // the next patch (cin*256 <= 512 floats, one per thread) is fetched while the current one is processed
@@ -224,12 +243,12 @@ __global__ __launch_bounds__(NTH) void front_fwd_kernel(FrontArgs a) {
     conv1_relu<false>(L, a.cin, tid);
     lds_barrier();
     char *sv = a.saved ? a.saved + (long)pt * SV_BYTES : nullptr;
-    pool1<SPLIT, false>(L, tid, sv);
+    pool1<SPLIT, false, NT>(L, tid, sv);
     lds_barrier();
-    conv2_relu<SPLIT, false>(L, b2r, tid);
+    conv2_relu<SPLIT, false, NT>(L, b2r, tid);
     lds_barrier();
     // maxpool 2x2/1 -> output planes [100][32]
-    for (int e = tid; e < ON * 32; e += NTH) {
+    for (int e = tid; e < ON * 32; e += NT) {
       const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
       const float *s = L.c2r + (y * C2W + x) * 32 + c;
       const float v = fmaxf(fmaxf(s[0], s[32]), fmaxf(s[C2W * 32], s[C2W * 32 + 32]));
@@ -254,8 +273,8 @@ struct FrontMapArgs {
   int H, W, tiles_x, tiles_y;
 };
 
-template <int SPLIT>
-__global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
+template <int SPLIT, int NT>
+__global__ __launch_bounds__(NT) void front_fwd_map_kernel(FrontMapArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int cin = a.f.cin, tid = threadIdx.x;
   char *p = lds;
@@ -269,12 +288,12 @@ __global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
   L.w2h = take(KS2 * 32 * 32 * 2);
   L.w2l = take(KS2 * 32 * 32 * 2);
   L.c2r = (float *)take(sizeof(float) * C2N * 32);
-  for (int e = tid; e < 8 * cin * 25; e += NTH) {  // [co][ci][tap] -> [ci][tap][co]
+  for (int e = tid; e < 8 * cin * 25; e += NT) {  // [co][ci][tap] -> [ci][tap][co]
     const int t = e % 25, ci = (e / 25) % cin, co = e / (25 * cin);
     L.w1[(ci * 25 + t) * 8 + co] = a.f.w1[e];
   }
   if (tid < 8) L.w1[8 * cin * 25 + tid] = a.f.b1[tid];
-  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NTH) {
+  for (int e = tid; e < KS2 * 32 * 32 / 8; e += NT) {
     const int d = w2_lds_chunk(e);
     reinterpret_cast<uint4 *>(L.w2h)[d] = reinterpret_cast<const uint4 *>(a.f.w2h)[e];
     if (SPLIT == 3) reinterpret_cast<uint4 *>(L.w2l)[d] = reinterpret_cast<const uint4 *>(a.f.w2l)[e];
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
     const int pt = (int)(wk / ntile), tile = (int)(wk % ntile);
     const int oy0 = (tile / a.tiles_x) * OW, ox0 = (tile % a.tiles_x) * OW;
     // 20x20 window of the patch: local (r, c) = image (oy0 + r - 2, ox0 + c - 2)
-    for (int e = tid; e < cin * MXW * MXW; e += NTH) {
+    for (int e = tid; e < cin * MXW * MXW; e += NT) {
       const int ci = e / (MXW * MXW), r = (e / MXW) % MXW, c = e % MXW;
       const int iy = oy0 + r - 2, ix = ox0 + c - 2;
       L.xs[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? a.f.x[(((long)pt * cin + ci) * H + iy) * W + ix] : 0.f;
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
     }
     lds_barrier();
     // pool1 over the whole 15x15 a1 window: local (r, c) = a1 map (oy0 + r - 1, ox0 + c - 1); outside the map = conv2's zero padding
-    for (int e = tid; e < A1PW * A1PW * 8; e += NTH) {
+    for (int e = tid; e < A1PW * A1PW * 8; e += NT) {
       const int c = e & 7, q = e >> 3, r = q / A1PW, cc = q % A1PW;
       const int ay = oy0 + r - 1, ax = ox0 + cc - 1;
       float v = 0.f;
@@ -327,9 +346,9 @@ __global__ __launch_bounds__(NTH) void front_fwd_map_kernel(FrontMapArgs a) {
       if (SPLIT == 3) *reinterpret_cast<uint16_t *>(L.a1l + q * 16 + 2 * c) = f2bf(v - bf2f(h));
     }
     lds_barrier();
-    conv2_relu<SPLIT, false>(L, b2r, tid);
+    conv2_relu<SPLIT, false, NT>(L, b2r, tid);
     lds_barrier();
-    for (int e = tid; e < ON * 32; e += NTH) {  // maxpool 2x2/1 -> the in-map part of the output tile
+    for (int e = tid; e < ON * 32; e += NT) {  // maxpool 2x2/1 -> the in-map part of the output tile
       const int c = e & 31, q = e >> 5, y = q / OW, x = q % OW;
       if (oy0 + y < Ho && ox0 + x < Wo) {
         const float *s2 = L.c2r + (y * C2W + x) * 32 + c;
@@ -1329,6 +1348,12 @@ int crw_enc_front_pack(const float *w2, uint16_t *fwd_hi, uint16_t *fwd_lo, uint
   return check_launch();
 }
 
+// threads per workgroup of the forward kernels: 512 (two workgroups per CU), CRW_FRONT_NT=1024 for the one-workgroup form
+static int front_fwd_threads() {
+  static const int nt = [] { const char *e = getenv("CRW_FRONT_NT"); return e && atoi(e) == 1024 ? 1024 : 512; }();
+  return nt;
+}
+
 size_t crw_enc_front_saved_bytes(int P) { return P < 1 ? 0 : (size_t)P * SV_BYTES; }
 
 int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1, const float *b1,
@@ -1340,9 +1365,14 @@ int crw_enc_front_fwd(int split, const float *x, int P, int cin, const float *w1
   if (split == 3 && (!w2_lo || !y_lo)) return CRW_EINVAL;
   FrontArgs a{x, w1, b1, w2_hi, w2_lo, b2, y_hi, y_lo, P, cin, static_cast<char *>(saved)};
   const size_t lds = fwd_lds_bytes(cin);
-  const int grid = P < 512 ? P : 512;  // two 1024-thread workgroups (60 KB of LDS each) per CU
-  if (split == 3) hipLaunchKernelGGL(front_fwd_kernel<3>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(front_fwd_kernel<1>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
+  const int grid = P < 512 ? P : 512;  // two workgroups (60 KB of LDS each) per CU
+  if (front_fwd_threads() == 1024) {
+    if (split == 3) hipLaunchKernelGGL((front_fwd_kernel<3, 1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((front_fwd_kernel<1, 1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, a);
+  } else {
+    if (split == 3) hipLaunchKernelGGL((front_fwd_kernel<3, 512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((front_fwd_kernel<1, 512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  }
   return check_launch();
 }
 
@@ -1361,16 +1391,23 @@ int crw_enc_front_fwd_map(int split, const float *x, int P, int cin, int H, int 
   const size_t lds = r(4 * cin * MXW * MXW) + r(4 * (8 * cin * 25 + 8)) + r(4 * MC1W * MC1W * 8) + 2 * r(A1PW * A1PW * 16) +
                      2 * r(KS2 * 32 * 32 * 2) + r(4 * C2N * 32);
   const long nwork = (long)P * tx * ty;
-  const int grid = nwork < 512 ? (int)nwork : 512;  // two 1024-thread workgroups per CU
-  static bool attr3 = false, attr1 = false;
-  bool &attr = split == 3 ? attr3 : attr1;
-  const void *fn = split == 3 ? (const void *)front_fwd_map_kernel<3> : (const void *)front_fwd_map_kernel<1>;
-  if (!attr && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CRW_EHIP;
-    attr = true;
+  const int grid = nwork < 512 ? (int)nwork : 512;  // two workgroups per CU
+  const bool big = front_fwd_threads() == 1024;
+  static bool attr[4] = {false, false, false, false};
+  const void *fns[4] = {(const void *)front_fwd_map_kernel<1, 512>, (const void *)front_fwd_map_kernel<3, 512>,
+                        (const void *)front_fwd_map_kernel<1, 1024>, (const void *)front_fwd_map_kernel<3, 1024>};
+  const int which = (big ? 2 : 0) + (split == 3 ? 1 : 0);
+  if (!attr[which] && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CRW_EHIP;
+    attr[which] = true;
   }
-  if (split == 3) hipLaunchKernelGGL(front_fwd_map_kernel<3>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(front_fwd_map_kernel<1>, dim3(grid), dim3(NTH), lds, (hipStream_t)stream, a);
+  if (big) {
+    if (split == 3) hipLaunchKernelGGL((front_fwd_map_kernel<3, 1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((front_fwd_map_kernel<1, 1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, a);
+  } else {
+    if (split == 3) hipLaunchKernelGGL((front_fwd_map_kernel<3, 512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((front_fwd_map_kernel<1, 512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  }
   return check_launch();
 }
 
