@@ -24,4 +24,8 @@ prof() { # name, bench args...
 }
 prof default --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-probe
 prof resnet --model 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-probe
+# the same step with the side stream off: per-kernel durations of kernels running ALONE (with it on they overlap and do not add up)
+export CRW_RN_STREAMS=0
+prof resnet_serial --model 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-probe
+unset CRW_RN_STREAMS
 prof labelprop --workload labelprop --steps 3 --warmup 1 --no-events
