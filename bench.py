@@ -26,6 +26,7 @@ import torch
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s (about 6 TB/s is what streaming kernels reach)
 PEAK_HBM_GBS = 8000.0
 
 H_RG, W_RG, T_SEQ, PATCH, OVERLAP, TAU = 512, 4096, 32, (16, 16), (8, 0), 0.01
@@ -153,6 +154,9 @@ def resnet_event_kernels(ev, P, steps):
         kind, mode = key[0], key[1]
         if kind == "rn_conv":
             _, _, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad = key
+            # algorithmic HBM bytes: the source planes once (hi + lo = 4 B per element) + the fp32 destination once (the fused
+            # epilogues of the backward-data products read more -- mask, Z, the other branch's gradient: not counted)
+            nbytes = 4.0 * P * (Hs * Ws * Cs + Hd * Wd * N)
             if mode == crw_hip.RN_FWD:
                 alg, ex = 2.0 * P * _rn_pairs(Hs, Ws, Hd, Wd, k, stride, pad) * Cs * N, 1.0
                 name = f"rn_conv_spec_kernel fwd {Hs}x{Ws}x{Cs} -> {Hd}x{Wd}x{N} k{k}/s{stride}"
@@ -170,6 +174,7 @@ def resnet_event_kernels(ev, P, steps):
                 name = "rn_stem_bwd_kernel 64 -> 3 (patch per wave; rn_conv_kernel on Toeplitz planes at other patch sizes)"
         else:
             _, _, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad = key
+            nbytes = 4.0 * P * (Hin * Win * Cin + Hout * Wout * Cout)  # both operands' planes once
             if mode == crw_hip.RN_FWD:
                 alg, ex = 2.0 * P * _rn_pairs(Hin, Win, Hout, Wout, k, stride, pad) * Cin * Cout, 1.0
                 name = f"rn_wgrad_kernel {Hin}x{Win}x{Cin} -> {Hout}x{Wout}x{Cout} k{k}/s{stride} (+ slab sum)"
@@ -177,14 +182,23 @@ def resnet_event_kernels(ev, P, steps):
                 alg, ex = 2.0 * P * Hout * Wout * 147 * 64, 256.0 / 147.0
                 name = "rn_stem_wgrad_kernel 7x7/2 (+ slab sum) (patch per wave pair; rn_wgrad_kernel at other patch sizes)"
         kms = sum(pairs) / len(pairs)  # ms of every timed launch (crw_rn_timing_read)
-        out.append({"kernel": name, "bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"],
-                    "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                    "mfma_executed_tflops": alg * 3 * ex / (kms * 1e-3) / 1e12,
-                    "mfma_executed_frac": alg * 3 * ex / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                    "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // steps, "timed_launches": len(pairs),
-                    "algorithmic_flops_per_launch": alg,
-                    "note": "achieved = algorithmic (fp32-equivalent, in-map taps only) flops / mean HIP-event time of this kernel's launches "
-                            "INSIDE the timed steps; every product is 3 bf16 MFMAs on hi/lo operand pairs"})
+        mfma_frac = alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]
+        hbm_gbps = nbytes / (kms * 1e-3) / 1e9
+        hbm_frac = hbm_gbps / HBM_PEAK_GBPS
+        e = {"kernel": name, "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // steps, "timed_launches": len(pairs),
+             "algorithmic_flops_per_launch": alg, "algorithmic_bytes_per_launch": nbytes,
+             "mfma_frac": mfma_frac, "mfma_tflops": alg / (kms * 1e-3) / 1e12,
+             "mfma_executed_tflops": alg * 3 * ex / (kms * 1e-3) / 1e12,
+             "mfma_executed_frac": alg * 3 * ex / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+             "hbm_frac": hbm_frac, "hbm_GBps": hbm_gbps,
+             "note": "algorithmic (fp32-equivalent, in-map taps only) flops and HBM bytes / mean HIP-event time of this kernel's launches "
+                     "INSIDE the timed steps (the side stream is active: a launch that shares the chip with another one takes longer than "
+                     "alone); every product is 3 bf16 MFMAs on hi/lo operand pairs; `bound` = the roof the kernel is closer to"}
+        if hbm_frac > mfma_frac:  # the small-K products (1x1 shortcuts, layer1) move more bytes per flop than the matrix roof's ridge
+            e.update({"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac})
+        else:
+            e.update({"bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": mfma_frac})
+        out.append(e)
     out.sort(key=lambda k_: -k_["launch_us"] * k_["launches_per_step"])
     # HBM traffic of layer1's weight gradient (the dominant matrix-core kernel of the step) from the committed in-step PMC passes
     # (profiles/r03_pmc_resnet.json: rn_wgrad_kernel<64, 64, 32> is launched exactly twice per step, for layer1's two convolutions),

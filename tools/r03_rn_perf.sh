@@ -8,7 +8,7 @@ if [ -n "$TESTENV" ]; then  # the parity tests once more under an env knob, e.g.
 fi
 run() { timeout -k 10 300 env "$@" python bench.py --model 1 --no-probe --no-cpu-baseline > $O/bench_m1.log 2>&1; grep '^{' $O/bench_m1.log | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$*', 'ms/step %.3f' % d['ms_per_step'], 'loss', d['config']['loss'])
-for k in d.get('roofline_kernels', [])[:40]: print('   %-72s x%d %7.1f us  alg %.3f exec %.3f' % (k['kernel'][:72], k['launches_per_step'], k['launch_us'], k['frac'], k['mfma_executed_frac']))
+for k in d.get('roofline_kernels', [])[:40]: print('   %-72s x%d %7.1f us  %s %.3f (mfma %.3f exec %.3f hbm %.3f)' % (k['kernel'][:72], k['launches_per_step'], k['launch_us'], k['bound'], k['frac'], k['mfma_frac'], k['mfma_executed_frac'], k['hbm_frac']))
 "; }
 run CRW_DEFAULT=1
 for kv in "$@"; do run $kv; done
