@@ -1,0 +1,35 @@
+"""The kernel variants behind environment switches (read once per process, so each runs in a child process): the non-default
+schedules and kernels that DESIGN.md quotes A/B numbers for must stay correct, not only the defaults the rest of the suite runs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+RESNET = "tests/test_resnet_hip.py"
+PARITY = "tests/test_hip_parity.py"
+VARIANTS = [
+    # Resnet products on the all-in-one 4-wave workgroups instead of the split-role ones (csrc/resnet_gemm.hip: launch_rn_conv)
+    ("CRW_RN_SPEC", "0", RESNET, "native_and_stepwise or training_step or conv_forward_backward"),
+    # BatchNorm-backward sums as a pass of their own instead of the products' LDS-staged epilogue (csrc/resnet_net.hip)
+    ("CRW_RN_FUSE_RED", "0", RESNET, "native_and_stepwise or training_step or matches_pytorch_modules"),
+    # everything on the caller's stream (no side stream)
+    ("CRW_RN_STREAMS", "0", RESNET, "native_and_stepwise or training_step"),
+    # forward front end on one 1024-thread workgroup per CU (csrc/encoder_front.hip)
+    ("CRW_FRONT_NT", "1024", PARITY, "encoder_front_kernels or encoder_inference_trunk"),
+    # bf16 chain GEMM with its A operand staged through registers (csrc/gemm_bf16.hip)
+    ("CRW_GEMM_REGA", "1", PARITY, "gemm_bf16"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,value,path,expr", VARIANTS, ids=[f"{v[0]}={v[1]}" for v in VARIANTS])
+def test_kernel_variant_behind_env_switch(name, value, path, expr):
+    env = dict(os.environ, **{name: value})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, path), "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and " failed" not in r.stdout, tail
