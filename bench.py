@@ -566,7 +566,10 @@ def main():
                         "ms_per_step_min": min(rep_elapsed) / args.steps * 1e3, "ms_per_step_max": max(rep_elapsed) / args.steps * 1e3,
                         "ms_per_step_all": [e / args.steps * 1e3 for e in rep_elapsed]},
             "dtype": {"bf16x3": "f32 (conv2-5 multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; everything else fp32)",
-                      "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32"}[args.convs if args.model == 0 else ("bf16x3" if getattr(enc, "hip_convs", None) else "torch")],
+                      "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32",
+                      "resnet": "f32 (every convolution and the linear head multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; "
+                                "BatchNorm statistics merged in fp64; everything else fp32)"}[
+                          args.convs if args.model == 0 else ("resnet" if getattr(enc, "hip_convs", None) else "torch")],
             "data": "synthetic",
             "config": {"workload": f"one synthetic {H_RG}x{W_RG} radargram per GPU per step = {B} items "
                                    f"[T={T},N={N},{PATCH[0]}x{PATCH[1]}] (patch {PATCH[0]}x{PATCH[1]}, overlap {OVERLAP}), tau={TAU}, "
