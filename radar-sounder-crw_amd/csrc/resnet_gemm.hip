@@ -820,9 +820,13 @@ int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
   // the stem forward 20 % faster than on two 64-deep stages), two stages for the 128-column tiles (64 KB; step 6.9 -> 6.6 ms);
   // the long single segment of the stem's backward-data product prefers two 64-deep stages.  CRW_RN_BK = 64 | 32 | 322 forces one.
   // Default: the split-role kernel (4 MFMA waves + 4 LDS-DMA waves, two 512-thread workgroups per CU, two 32-deep stages): the step
-  // measured 1.1-1.4 % faster than on rn_conv_kernel's 4-wave workgroups (4.75 -> 4.69 ms); deeper rings (one workgroup per CU) and
-  // 256-patch tiles on 8 waves (rn_conv_kernel<..., TM = 256>: a quarter fewer staged bytes per flop, but one workgroup per CU)
-  // measured no faster: 4.77 / 4.82 / 4.74 ms.  CRW_RN_SPEC=0 selects rn_conv_kernel, =3 / =4 the deeper rings.
+  // measured 1.1-1.4 % faster than on rn_conv_kernel's 4-wave workgroups (4.75 -> 4.69 ms).  Measured SLOWER: deeper rings with one
+  // workgroup per CU (CRW_RN_SPEC=3 / 4: 4.77 / 4.82 ms) and 256-patch tiles on 8 waves (CRW_RN_TM=256, rn_conv_kernel<..., TM = 256>:
+  // a quarter fewer staged bytes per flop but one workgroup per CU, 4.98 ms; forward 3x3x128 product 87 -> 110 us): what these
+  // short-k products need is the second workgroup that covers prologue and epilogue.  CRW_RN_SPEC=0 selects rn_conv_kernel.
+  static const int tm = [] { const char *e = getenv("CRW_RN_TM"); return e ? atoi(e) : 128; }();  // 256: 256-patch tiles on 8 waves
+  if (tm == 256 && a.mtiles % 2 == 0 && a.mode != RN_MODE_STEM_BWD)
+    return wide ? launch_conv_cfg<128, 32, 2, 256>(a, s) : launch_conv_cfg<64, 32, 2, 256>(a, s);
   static const int spec = [] { const char *e = getenv("CRW_RN_SPEC"); return e ? atoi(e) : 2; }();
   if (spec && a.mode != RN_MODE_STEM_BWD) {
     if (spec == 3) return wide ? launch_conv_spec<128, 32, 3>(a, s) : launch_conv_spec<64, 32, 3>(a, s);

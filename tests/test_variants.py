@@ -13,6 +13,8 @@ PARITY = "tests/test_hip_parity.py"
 VARIANTS = [
     # Resnet products on the all-in-one 4-wave workgroups instead of the split-role ones (csrc/resnet_gemm.hip: launch_rn_conv)
     ("CRW_RN_SPEC", "0", RESNET, "native_and_stepwise or training_step or conv_forward_backward"),
+    # 256-patch tiles on 8 waves, one workgroup per CU (measured slower; kept as the A/B partner DESIGN quotes)
+    ("CRW_RN_TM", "256", RESNET, "native_and_stepwise or training_step or conv_forward_backward"),
     # BatchNorm-backward sums as a pass of their own instead of the products' LDS-staged epilogue (csrc/resnet_net.hip)
     ("CRW_RN_FUSE_RED", "0", RESNET, "native_and_stepwise or training_step or matches_pytorch_modules"),
     # everything on the caller's stream (no side stream)
