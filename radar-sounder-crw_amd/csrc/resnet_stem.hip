@@ -270,8 +270,11 @@ __global__ __launch_bounds__(512) void rn_stem_wgrad_kernel(const float *__restr
 }
 
 // ================================================================================================ backward-data + stem sums
-// 8 waves, one patch per wave and iteration.  LDS: W^T fragments (56 KB) + a [81][32] fp32 strip per wave (one kernel row of G).
-constexpr int GSTRIP = 81 * 32 * 4;
+// 8 waves, one patch per wave and iteration.  LDS: W^T fragments (56 KB) + a [81][32 (+4 pad)] fp32 strip per wave (one kernel row of G).
+// strip rows on a 36-float stride: the four row groups of an accumulator store land on disjoint banks and the col2im reads are at most
+// 2-way conflicted (on the natural 32-float stride both were 4-way: PMC LDS conflict share 0.51)
+constexpr int GS_LD = 36;
+constexpr int GSTRIP = 81 * GS_LD * 4;
 
 template <int CIN>
 __global__ __launch_bounds__(512) void rn_stem_bwd_kernel(const float *__restrict__ x, const float *__restrict__ stem,
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512) void rn_stem_bwd_kernel(const float *__restric
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     okj[j] = owner && oxa + j <= oxb;
-    gofs[j] = okj[j] ? (oxa + j) * 32 + (ix + 3 - 2 * (oxa + j)) * 4 + c : 0;
+    gofs[j] = okj[j] ? (oxa + j) * GS_LD + (ix + 3 - 2 * (oxa + j)) * 4 + c : 0;
   }
 
   const int gw = blockIdx.x * 8 + wave, tw = gridDim.x * 8;
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(512) void rn_stem_bwd_kernel(const float *__restric
           for (int r = 0; r < 4; ++r) {
             const int o = olo + 16 * i + (lane >> 4) * 4 + r;
             if (o < 81) {
-              gs[o * 32 + (lane & 15)] = acc[i][0][r];
-              gs[o * 32 + 16 + (lane & 15)] = acc[i][1][r];
+              gs[o * GS_LD + (lane & 15)] = acc[i][0][r];
+              gs[o * GS_LD + 16 + (lane & 15)] = acc[i][1][r];
             }
           }
         // col2im: output row oy adds to map row iy = 2 oy + ky - 3; a map column receives from at most four output columns
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(512) void rn_stem_bwd_kernel(const float *__restric
           for (int j = 0; j < 4; ++j) {
             const int o = oy * 9 + oxa + j;
             const bool ok = okj[j] && o >= olo && o < ohi;
-            const float v = gs[ok ? oy * 288 + gofs[j] : 0];
+            const float v = gs[ok ? oy * (9 * GS_LD) + gofs[j] : 0];
             sum += ok ? v : 0.f;
           }
           tmp[oy] = sum;
