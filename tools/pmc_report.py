@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic and matrix-pipe occupancy INSIDE the training step from the three PMC passes of tools/r02_pmc_run.sh.
-usage: python tools/pmc_report.py gpurun_out/r02pmc profiles/r02   -> profiles/r02_pmc_in_step_traffic.json, profiles/r02_pmc_in_step.json
+usage: python tools/pmc_report.py gpurun_out/r03pmc_cnn profiles/r03   -> profiles/r03_pmc_in_step_traffic.json, profiles/r03_pmc_in_step.json
+(round 2: gpurun_out/r02pmc profiles/r02; passes: tools/r03_pmc_cnn.sh / tools/r02_pmc_run.sh)
 FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM):
 hbm_read_bytes = 2 * 1024 * FETCH_SIZE, hbm_write_bytes = 1024 * WRITE_SIZE.  Algorithmic bytes = the planes a kernel must read /
 write once at the default workload (P = 16128 patches of 100 pixels; bf16 hi + lo = 4 B per element, hi only = 2 B)."""
@@ -14,7 +15,7 @@ fetch, write, mfma = (json.load(open(f"{src}/{n}.json")) for n in ("FETCH_SIZE",
 
 def algorithmic(name):
     """-> (kind, cin, cout, read bytes, write bytes) of a hand-written conv kernel, else None."""
-    m = re.match(r"conv3x3_kernel<3, (\d+), (\d+), (\d), \d, false>", name)
+    m = re.match(r"conv3x3_kernel<3, (\d+), (\d+), (\d), \d, false(?:, \d+)?>", name)
     if m:
         a, b, mode = int(m.group(1)), int(m.group(2)), int(m.group(3))
         if mode == 0:  # forward cin=a -> cout=b; conv5 keeps only the hi plane of its output
