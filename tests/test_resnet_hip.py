@@ -366,6 +366,31 @@ def test_resnet_native_and_stepwise_paths_agree(hip):
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=1e-4 * max(1e-6, q.grad.abs().max().item()), msg=lambda m: f"{k}: {m}")
 
 
+def test_resnet_forward_without_grad_is_the_same_forward(hip):
+    """Inference as the reference runs it (scripts/test/test_all.py: the default encoder is the Resnet, never `.eval()`'d, under
+    `torch.no_grad()`): the native forward, batch statistics and running-statistics update included, bit for bit the forward of
+    a training step; through `utils.propagate` it yields a full label map."""
+    import copy
+    import encoder as crw_encoder
+    import utils as crw_utils
+    from imported.labelprop import LabelPropVOS_CRW
+    torch.manual_seed(5)
+    a = crw_encoder.Resnet(False).cuda()
+    b = copy.deepcopy(a)
+    x = torch.randn(6 * 20, 1, 16, 16).cuda()
+    ya = a(x)
+    with torch.no_grad():
+        yb = b(x)
+    assert not yb.requires_grad and torch.equal(ya.detach(), yb)
+    for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(p, q), k
+    seq = x.reshape(6, 20, 16, 16)
+    seg = (torch.arange(20 * 8 + 8)[:, None] * 4 // (20 * 8 + 8)).float().repeat(1, 16).cuda()
+    pred, xent, _ = crw_utils.propagate(seq, seg, b, LabelPropVOS_CRW(dict(CXT_SIZE=4, RADIUS=5, TEMP=0.1, KNN=5)), 4, False, False)
+    assert pred.shape == (20, 6) and xent.shape == (20, 5) and torch.isfinite(pred).all()
+    assert torch.equal(pred[:, 0], crw_utils.seed_labels(seg, 20))
+
+
 def test_resnet_native_pass_is_reproducible(hip):
     """Side stream, last-block merges and split slabs must not make the result depend on the schedule: the same step run five times
     (fresh module copies, same input) gives bit-identical features, running statistics and gradients."""
