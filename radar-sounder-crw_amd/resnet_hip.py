@@ -25,6 +25,13 @@ def supported(x, net):
             and net.training and net.bn0.momentum is not None)
 
 
+def check_batch(x):
+    """nn.BatchNorm2d refuses a training batch with ONE value per channel (torch.nn.functional._verify_batch_size): layer4's map is
+    1 x 1 at 16x16 patches, so a single patch raises there in the reference -- same error here, before any launch."""
+    if x.shape[0] == 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([1, 512, 1, 1])}")
+
+
 def _out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
@@ -51,6 +58,7 @@ class HipResnetNative(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, *params):
+        check_batch(x)
         x = x.contiguous()
         bns = _bn_modules(net)
         prm = [p.detach() for p in params]
@@ -71,6 +79,7 @@ class HipResnetNative(torch.autograd.Function):
 class HipResnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, *params):
+        check_batch(x)
         x = x.contiguous()
         P, cin, h, w = x.shape
         body = net.model

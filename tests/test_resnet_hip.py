@@ -391,6 +391,22 @@ def test_resnet_forward_without_grad_is_the_same_forward(hip):
     assert torch.equal(pred[:, 0], crw_utils.seed_labels(seg, 20))
 
 
+def test_resnet_single_patch_batch_raises_like_batchnorm(hip):
+    """One 16x16 patch leaves layer4's BatchNorm one value per channel: nn.BatchNorm2d raises ValueError in training mode, and so
+    does the HIP path (before any launch) instead of normalising by sqrt(eps)."""
+    import copy
+    import encoder as crw_encoder
+    a = crw_encoder.Resnet(False).cuda()
+    b = copy.deepcopy(a)
+    b.hip_convs = None
+    x = torch.randn(1, 1, 16, 16).cuda()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        b(x)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        a(x)
+    assert torch.isfinite(a(torch.randn(2, 1, 16, 16).cuda())).all()
+
+
 def test_resnet_native_pass_is_reproducible(hip):
     """Side stream, last-block merges and split slabs must not make the result depend on the schedule: the same step run five times
     (fresh module copies, same input) gives bit-identical features, running statistics and gradients."""
