@@ -193,8 +193,9 @@ def crw_forward_torch(seq, sd, tau, use_pos_embed=False, dtype=None):
     return loss, A, emb
 
 
-def walk_loss_torch(emb, tau):
-    """Prefix-form walk in torch (differentiable); emb [B,T,N,C] raw -> (loss, A)."""
+def walk_loss_torch(emb, tau, At_out=None):
+    """Prefix-form walk in torch (differentiable, any device / dtype); emb [B,T,N,C] raw -> (loss, A).  `At_out`: a list that
+    receives every cycle product At_k (detached), k = 1..T-2."""
     import torch
     B, T, N, C = emb.shape
     eh = emb / emb.norm(dim=-1, keepdim=True).clamp_min(EPS_NORM)
@@ -212,6 +213,8 @@ def walk_loss_torch(emb, tau):
         else:
             Lt, R = Gt[:, k - 1] @ Lt, F[:, k - 1] @ R
         At = Lt.transpose(1, 2) @ R
+        if At_out is not None:
+            At_out.append(At.detach())
         lse = torch.logsumexp(At, -1)
         loss = loss - (torch.diagonal(At, dim1=1, dim2=2) - lse).sum() / (B * N)
     return loss / N, A

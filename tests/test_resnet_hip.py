@@ -282,11 +282,68 @@ def _no_library_convs(monkeypatch):
     monkeypatch.setattr(torch.nn.Conv2d, "_conv_forward", boom)
 
 
+def _device_decisions(enc_stepwise, x):
+    """The discrete choices of the device's forward pass: the max-pool's arg-max code per window and every ReLU gate, read from
+    what the Python-driven schedule (`resnet_hip.HipResnetFn`, bit for bit the forward of the native pass -- asserted by
+    test_resnet_native_and_stepwise_paths_agree) saves for its backward.  Gates are `hi plane > 0`, exactly what the backward
+    kernels test."""
+    P = x.shape[0]
+    y = enc_stepwise(x)
+    sv = y.grad_fn.sv  # the autograd node of a custom Function is its ctx
+    _, _, _, _, _, _, H1, W1, H2, W2, _, _ = sv["geo"]
+
+    def gate(plane_hi, h, w, C):
+        return (plane_hi[:P].float() > 0).reshape(P, h, w, C).permute(0, 3, 1, 2).double()
+
+    dec = {"amax": sv["amax"][:P].reshape(P, H2 * W2, 64).permute(0, 2, 1).long(),  # [P, C, Ho*Wo], code = ky * 3 + kx
+           "pool": gate(sv["recs"][0]["Ain"][0], H2, W2, 64), "a": [], "out": []}
+    for b, r in zip(sv["blocks"], sv["recs"]):
+        dec["a"].append(gate(r["Aa"][0], b.hout, b.wout, b.cout))
+        dec["out"].append(gate(r["Aout"][0], b.hout, b.wout, b.cout))
+    return dec
+
+
+def _teacher_forced_forward(ref, x64, dec):
+    """`ref` (the fp64 PyTorch modules) with the device's discrete choices imposed: ReLU = multiplication by the recorded gate,
+    max-pool = the recorded window position.  Everything else (convolutions, train-mode BatchNorm on fp64 batch statistics,
+    average pool, head) is the module's own arithmetic.  Where the device's choice differs from the one fp64 would make, the two
+    candidates are within the arithmetic's ~1e-5 of each other (that is what a flip is), so the forward values move by that much;
+    the gradients then take the SAME routes on both sides and must agree entry by entry."""
+    body = ref.model
+    h = ref.relu0(ref.bn0(ref.fc0(x64)))  # the stem's gate feeds activations ~0 into the 7x7 product: not a routing decision
+    z1 = body.bn1(body.conv1(h))
+    P, C, H1, W1 = z1.shape
+    Ho, Wo = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+    win = TF.unfold(TF.pad(z1, (1, 1, 1, 1), value=float("-inf")), 3, stride=2).reshape(P, C, 9, Ho * Wo)
+    a = win.gather(2, dec["amax"][:, :, None, :]).reshape(P, C, Ho, Wo)
+    assert torch.isfinite(a).all()  # the device never picks a padding position
+    # how many of the device's choices differ from the ones this fp64 forward would make by itself (reported by the test)
+    live = (a.detach() > 0).reshape(P, C, Ho * Wo)  # (an all-negative window passes no gradient whichever position is named)
+    flips = {"argmax": int(((win.detach().argmax(2) != dec["amax"]) & live).sum()), "gates": int((live.reshape(a.shape).double() != dec["pool"]).sum())}
+    a = a * dec["pool"]
+    for i in range(4):
+        m = getattr(body, f"layer{i + 1}")[0]
+        za = m.bn1(m.conv1(a))
+        aa = za * dec["a"][i]
+        zb = m.bn2(m.conv2(aa))
+        s = zb + (a if m.downsample is None else m.downsample(a))
+        a = s * dec["out"][i]
+        flips["gates"] += int(((za.detach() > 0).double() != dec["a"][i]).sum()) + int(((s.detach() > 0).double() != dec["out"][i]).sum())
+    return body.fc(torch.flatten(body.avgpool(a), 1)), flips
+
+
 @pytest.mark.parametrize("pos_embed,P,path", [(False, 160, "bf16x3"), (True, 70, "bf16x3"), (False, 130, "stepwise")])
 def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path):
     """The whole encoder: HIP forward / backward / running statistics against the same module run on PyTorch ops in fp64.
     path "bf16x3" = the whole pass from native code (crw_rn_train_fwd / _bwd, what training uses), "stepwise" = the same
-    kernels launched one by one from Python (resnet_hip.HipResnetFn)."""
+    kernels launched one by one from Python (resnet_hip.HipResnetFn).
+
+    Two references.  FREE-RUNNING fp64 modules: features, running statistics, and direction + norm of every gradient (an fp32-grade
+    forward and an fp64 one may pick different arg-max pixels / ReLU gates where two candidates differ by less than ~1e-5, which
+    re-routes single gradient contributions: entry-wise equality is not defined against this reference).  TEACHER-FORCED fp64
+    modules (the device's recorded arg-max codes and gates imposed on the fp64 forward, `_teacher_forced_forward`): EVERY entry of
+    EVERY gradient within 5e-3 -- the proof that the entries the free-running comparison cannot hold are routing flips and
+    nothing else."""
     import copy
     import encoder as crw_encoder
     torch.manual_seed(3)
@@ -298,6 +355,9 @@ def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path
                 m.bias.uniform_(-0.2, 0.2)
     ref = copy.deepcopy(enc).double()
     ref.hip_convs = None
+    forced = copy.deepcopy(ref)
+    probe = copy.deepcopy(enc)
+    probe.hip_convs = "stepwise"
     enc.hip_convs = path
     x = torch.randn(P, 2 if pos_embed else 1, 16, 16).cuda()
     gy = torch.randn(P, 128).cuda()
@@ -311,34 +371,88 @@ def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path
         _no_library_convs(monkeypatch)
         y = enc(x)
         y.backward(gy)
+        dec = _device_decisions(probe.train(), x)
     monkeypatch.undo()
     torch.testing.assert_close(y.double(), y_ref.detach(), rtol=2e-3, atol=2e-3 * y_ref.abs().max().item())
-    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+    forced.train()
+    y_tf, flips = _teacher_forced_forward(forced, x.double(), dec)
+    y_tf.backward(gy.double())
+    # imposing the device's choices moves the fp64 forward by no more than the flips' own margins
+    torch.testing.assert_close(y_tf.detach(), y_ref.detach(), rtol=1e-3, atol=1e-3 * y_ref.abs().max().item())
+    print(f"routing decisions where the device and fp64 differ (P = {P}, {path}): {flips}")
+    for (k, p), (_, q), (_, t) in zip(enc.named_parameters(), ref.named_parameters(), forced.named_parameters()):
         assert p.grad is not None, k
-        scale = max(q.grad.abs().max().item(), 1e-6)
         if k == "fc0.bias":  # true gradient is zero (it feeds a BatchNorm); both sides hold rounding noise
             assert p.grad.abs().max().item() <= 1e-4 * max(1.0, enc.bn0.weight.grad.abs().max().item())
             continue
-        # The max-pool routes a gradient to the arg-max of its window: where two candidates differ by less than the arithmetic's
-        # ~1e-5, fp64 and any fp32-grade path may pick different pixels, which moves a few entries of the gradients BELOW the pool
-        # (one flipped window changes the 147 stem weights of its channel).  So: direction and norm tightly, single entries only at 80 %.
-        a, b_ = p.grad.double().flatten(), q.grad.flatten()
+        a, b_, c_ = p.grad.double().flatten(), q.grad.flatten(), t.grad.flatten()
+        # free-running reference: direction and norm (one flipped routing decision moves the 3-element gradients of the stem,
+        # sums over everything, by up to ~1 %)
         cos = float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
-        # (a ReLU gate whose pre-activation is within that ~1e-5 of zero flips the same way: single entries anywhere; and
-        # fc0.weight with one input channel is ill-conditioned, see test_rn_stem_matches_torch)
-        # With the random upstream gradient of this test every gradient is a random-walk sum, so one flipped routing decision
-        # moves the 3-element gradients of the stem (sums over everything) by up to ~1 %: the per-kernel tests above are the
-        # tight ones, this one checks the wiring of the whole network.
         below_pool = k in ("fc0.weight", "bn0.weight", "bn0.bias", "model.conv1.weight", "model.bn1.weight", "model.bn1.bias")
         assert cos > 0.999 and abs(float(a.norm() / b_.norm()) - 1) < (3e-2 if below_pool else 1e-2), (k, cos, float(a.norm()), float(b_.norm()))
-        close = (a - b_).abs() <= 5e-3 * scale + 5e-3 * b_.abs()
-        if a.numel() >= 1000:  # (the per-channel sums of the BatchNorm parameters: direction + norm only)
-            assert close.double().mean().item() >= 0.8, (k, close.double().mean().item())
+        # teacher-forced reference: every entry.  fc0.weight with ONE input channel survives only through BatchNorm's eps (the
+        # difference of sums ~1e5 times larger, test_rn_stem_matches_torch): held to that kernel test's 2e-2
+        tol = 2e-2 if (k == "fc0.weight" and not pos_embed) else 5e-3
+        scale = max(c_.abs().max().item(), 1e-6)
+        bad = (a - c_).abs() > tol * scale + tol * c_.abs()
+        assert not bad.any(), (k, int(bad.sum()), a.numel(), float(((a - c_).abs() / (scale + c_.abs())).max()))
     for (k, b), (_, c) in zip(enc.named_buffers(), ref.named_buffers()):
         if b.is_floating_point():
             torch.testing.assert_close(b.double(), c, rtol=1e-3, atol=1e-5, msg=lambda m: f"{k}: {m}")
         else:
             assert int(b) == int(c) == 1, k
+
+
+def test_resnet_step_at_bench_batch_matches_fp64(hip, monkeypatch):
+    """One step of the native pass at the batch bench.py times (`--model 1`: P = 8 * 32 * 63 = 16128 patches = 126 tiles of 128,
+    every patch slice and both streams in play) against the same modules in float64 on the GPU: features within 1e-4 of the
+    feature scale, running statistics, every gradient's norm within 1 % and direction (cosine) -- entry-wise equality against a
+    free-running reference is not defined (see test_resnet_hip_matches_pytorch_modules), so the teacher-forced reference is held
+    beside it: every entry of every gradient within 5e-3 at this size too."""
+    import copy
+    import encoder as crw_encoder
+    P = 8 * 32 * 63
+    torch.manual_seed(16128)
+    enc = crw_encoder.Resnet(False).cuda()
+    ref = copy.deepcopy(enc).double()
+    ref.hip_convs = None
+    forced = copy.deepcopy(ref)
+    probe = copy.deepcopy(enc)
+    probe.hip_convs = "stepwise"
+    g = torch.Generator(device="cuda").manual_seed(7)
+    # radargram-like patches: a smooth layered term under the noise (SURVEY section 8(d)), so that features are not pure noise
+    rows = torch.arange(16, device="cuda").float()[None, None, :, None]
+    x = torch.randn(P, 1, 16, 16, generator=g, device="cuda") + torch.sin(rows * 0.4 + torch.rand(P, 1, 1, 1, generator=g, device="cuda") * 6.28)
+    gy = torch.randn(P, 128, generator=g, device="cuda") / P
+    y_ref = ref.train()(x.double())
+    y_ref.backward(gy.double())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _no_library_convs(monkeypatch)
+        y = enc.train()(x)
+        y.backward(gy)
+        dec = _device_decisions(probe.train(), x)
+    monkeypatch.undo()
+    fscale = y_ref.detach().abs().max().item()
+    err = (y.double() - y_ref.detach()).abs().max().item()
+    assert err <= 1e-4 * fscale, (err, fscale)
+    y_tf, flips = _teacher_forced_forward(forced.train(), x.double(), dec)
+    y_tf.backward(gy.double())
+    print(f"P = {P}: feature error {err / fscale:.2e} of scale; routing decisions where the device and fp64 differ: {flips}")
+    for (k, p), (_, q), (_, t) in zip(enc.named_parameters(), ref.named_parameters(), forced.named_parameters()):
+        if k == "fc0.bias":
+            continue
+        a, b_, c_ = p.grad.double().flatten(), q.grad.flatten(), t.grad.flatten()
+        cos = float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
+        assert cos > 0.9999 and abs(float(a.norm() / b_.norm()) - 1) < 1e-2, (k, cos, float(a.norm()), float(b_.norm()))
+        tol = 2e-2 if k == "fc0.weight" else 5e-3
+        scale = max(c_.abs().max().item(), 1e-30)
+        bad = (a - c_).abs() > tol * scale + tol * c_.abs()
+        assert not bad.any(), (k, int(bad.sum()), a.numel(), float(((a - c_).abs() / (scale + c_.abs())).max()))
+    for (k, b), (_, c) in zip(enc.named_buffers(), ref.named_buffers()):
+        if b.is_floating_point():
+            torch.testing.assert_close(b.double(), c, rtol=1e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")
 
 
 def test_resnet_native_and_stepwise_paths_agree(hip):
