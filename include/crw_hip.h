@@ -37,7 +37,7 @@ extern "C" {
 /* Bumps when a signature changes or an entry point is added.  The ONE place the number is written: crw_abi_version() returns
  * it, the ctypes binding (crw_hip.ABI_VERSION) parses it from this header, and __graft_entry__.build() / the host tests compare
  * the two. */
-#define CRW_ABI_VERSION 5
+#define CRW_ABI_VERSION 6
 
 #define CRW_OK 0
 #define CRW_EINVAL 1     /* bad shape / null pointer / unsupported size            */
@@ -237,8 +237,10 @@ int crw_rn_padded_patches(int P);
 int crw_rn_pack_conv(const float *w, int cout, int cin, int kh, int kw, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *bwd_hi,
                      uint16_t *bwd_lo, crw_stream_t stream);
 /* stem convolution model.conv1 [64][3][7][7] (src/encoder.py:185) for h x w patches: forward planes [64][256] and the Toeplitz
- * planes [(h+2)][64][crw_rn_stem_toeplitz_ld(w)] of its backward-data product */
+ * planes [(h+2)][crw_rn_stem_cols(w)][crw_rn_stem_toeplitz_ld(w)] of its backward-data product.  crw_rn_stem_cols(w) = 3 * (w + 2)
+ * rounded up to 64: the columns (ix * 3 + c) of one row of the stem's input gradient -- any patch width. */
 int crw_rn_stem_toeplitz_ld(int w);
+int crw_rn_stem_cols(int w);
 int crw_rn_pack_stem(const float *w1, int h, int w, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *toep_hi, uint16_t *toep_lo,
                      crw_stream_t stream);
 /* mode 0: forward of conv2d(kh x kw, stride, pad, no bias) -- a = input planes [Ppad][Hs*Ws][Cs], b = forward weight planes,
@@ -247,8 +249,8 @@ int crw_rn_pack_stem(const float *w1, int h, int w, uint16_t *fwd_hi, uint16_t *
  *         out = gradient on the input map [Ppad][Hd*Wd][N] (N = cin).
  * mode 2: stem forward (7x7, stride 2) -- a = the zero-padded 4-channel map of crw_rn_stem_fwd [Ppad][Hs][Ws][4], b = forward
  *         stem planes, out [Ppad][Hd*Wd][64].
- * mode 3: stem backward-data -- a = dZ planes [Ppad][Hs*Ws][64], b = Toeplitz planes, out [Ppad][Hd][64]: row iy holds the
- *         gradient of the (h+2) x (w+2) map at (iy, ix), channel c in column ix * 3 + c.
+ * mode 3: stem backward-data -- a = dZ planes [Ppad][Hs*Ws][64], b = Toeplitz planes, N = crw_rn_stem_cols(w), out [Ppad][Hd][N]:
+ *         row iy holds the gradient of the (h+2) x (w+2) map at (iy, ix), channel c in column ix * 3 + c.
  * part (may be NULL): crw_rn_conv_part_floats(P, Hd*Wd, N) floats of per-tile column sums / sums of squares for crw_rn_bn_stats. */
 size_t crw_rn_conv_part_floats(int P, int G, int N);
 int crw_rn_conv(int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int kh, int kw, int stride, int pad,
@@ -329,7 +331,10 @@ int crw_rn_colsum(const float *x, int rows, int C, float *out, void *ws, size_t 
 
 /* The whole encoder from native code: one call runs every launch of the forward (backward) pass on one workspace -- what the
  * host modules use (resnet_hip.py); the entry points above remain as the building blocks the tests exercise one by one.
- * Patches x [P][cin][16][16] (cin = 1, or 2 with pos_embed).  prm / grads: the CRW_RN_NPARAM parameter tensors (gradients) in
+ * Patches x [P][cin][h][w] of any size (cin = 1, or 2 with pos_embed); 16 x 16 -- the reference's default, scripts/train.py:24 --
+ * takes the patch-per-wave stem kernels, other sizes (32 x 32: scripts/test/test_mc1.py:19) the gathered stem products, and where
+ * layer4's map has more than one pixel the global average pool + linear head (src/encoder.py:264-266) run as one product over
+ * that map.  prm / grads: the CRW_RN_NPARAM parameter tensors (gradients) in
  * nn.Module.named_parameters() order -- fc0.weight, fc0.bias, bn0.weight, bn0.bias, model.conv1.weight, model.bn1.{weight,bias},
  * model.layer{1..4}.0.{conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias [, downsample.0.weight,
  * downsample.1.weight, downsample.1.bias]}, model.fc.weight, model.fc.bias; run_mean / run_var (NULL together: not updated): the
@@ -343,6 +348,10 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
                      float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
 int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *grads,
                      void *ws, size_t ws_bytes, crw_stream_t stream);
+/* The same forward with every BatchNorm in EVAL mode (nn.Module.eval(): normalise by the running statistics, update nothing) --
+ * what the reference's scripts/test/test.py:42 runs before utils.propagate.  ws: crw_rn_train_ws_bytes. */
+int crw_rn_eval_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, const float *const *run_mean,
+                    const float *const *run_var, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
 /* Diagnostic (bench.py's in-step roofline; the one stateful corner of the library, not thread-safe): while enabled, every
  * matrix-core launch of crw_rn_train_fwd / _bwd is bracketed by two HIP events on the launch stream.  After synchronising the
  * stream, crw_rn_timing_read fills up to `max` records in launch order and returns how many were taken; enable(…) resets.

@@ -106,6 +106,8 @@ SIGNATURES = {
     "crw_rn_train_ws_bytes": (_c_sz, [_c_int] * 4),
     "crw_rn_train_fwd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
     "crw_rn_train_bwd": (_c_int, [_p, _p] + [_c_int] * 4 + [_p, _p, _p, _c_sz, _p]),
+    "crw_rn_eval_fwd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _p, _p, _c_sz, _p]),
+    "crw_rn_stem_cols": (_c_int, [_c_int]),
     "crw_rn_timing_enable": (_c_int, [_c_int]),
     "crw_rn_timing_read": (_c_int, [_p, _c_int]),
     "crw_gemm_bf16_ws_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
@@ -134,9 +136,22 @@ def lib():
     return _lib
 
 
+class CrwError(RuntimeError):
+    """A non-zero status from the C ABI.  `status` is the CRW_* code: CRW_EINVAL is the caller's data (shape / size / null
+    pointer), CRW_EWORKSPACE and CRW_EHIP are failures of the HIP path itself (`hip_error` = the runtime's last error code)."""
+
+    def __init__(self, what, status, hip_error):
+        super().__init__(f"{what} failed: {_ERR.get(status, status)} (hipError {hip_error})")
+        self.what, self.status, self.hip_error = what, status, hip_error
+
+    @property
+    def device_failure(self):
+        return self.status != CRW_EINVAL
+
+
 def _check(status, what):
     if status != CRW_OK:
-        raise RuntimeError(f"{what} failed: {_ERR.get(status, status)} (hipError {lib().crw_last_hip_error()})")
+        raise CrwError(what, status, lib().crw_last_hip_error())
 
 
 def _dev(t, name, dtype=torch.float32):
@@ -546,12 +561,17 @@ def rn_pack_conv(w):
     return fh, fl, bh, bl
 
 
+def rn_stem_cols(w):
+    """columns of one row of the stem's input gradient: 3 * (w + 2) rounded up to 64"""
+    return lib().crw_rn_stem_cols(int(w))
+
+
 def rn_pack_stem(w1, h, w):
-    """model.conv1 weight [64,3,7,7] -> (fwd_hi, fwd_lo [64*256], toeplitz_hi, toeplitz_lo [(h+2)*64*ld])."""
+    """model.conv1 weight [64,3,7,7] -> (fwd_hi, fwd_lo [64*256], toeplitz_hi, toeplitz_lo [(h+2)*rn_stem_cols(w)*ld])."""
     ld = lib().crw_rn_stem_toeplitz_ld(w)
     fh = torch.empty(64 * 256, dtype=_BF, device=w1.device)
     fl = torch.empty_like(fh)
-    th = torch.empty((h + 2) * 64 * ld, dtype=_BF, device=w1.device)
+    th = torch.empty((h + 2) * rn_stem_cols(w) * ld, dtype=_BF, device=w1.device)
     tl = torch.empty_like(th)
     _check(lib().crw_rn_pack_stem(_dev(w1.detach().contiguous(), "w1"), h, w, _bf(fh, "fh"), _bf(fl, "fl"), _bf(th, "th"),
                                   _bf(tl, "tl"), _stream()), "crw_rn_pack_stem")
@@ -796,7 +816,7 @@ def _ptr_array(tensors, n):
 
 
 def rn_train_fwd(x, params, run_mean, run_var, momentum, eps):
-    """x [P,cin,16,16]; params: the 42 parameter tensors in named_parameters() order; run_mean / run_var: the 13 BatchNorm buffer
+    """x [P,cin,h,w]; params: the 42 parameter tensors in named_parameters() order; run_mean / run_var: the 13 BatchNorm buffer
     pairs in module order (updated in place) -> (out [P,128], workspace kept for rn_train_bwd)."""
     P, cin, h, w = x.shape
     nbytes = lib().crw_rn_train_ws_bytes(P, cin, h, w)
@@ -808,6 +828,20 @@ def rn_train_fwd(x, params, run_mean, run_var, momentum, eps):
                                   _ptr_array(run_var, RN_NBN), float(momentum), float(eps), _dev(out, "out"), _ptr(ws), nbytes,
                                   _stream()), "crw_rn_train_fwd")
     return out, ws
+
+
+def rn_eval_fwd(x, params, run_mean, run_var, eps):
+    """the forward with every BatchNorm on its running statistics (module.eval()); nothing is updated -> out [P,128]"""
+    P, cin, h, w = x.shape
+    nbytes = lib().crw_rn_train_ws_bytes(P, cin, h, w)
+    if nbytes == 0:
+        raise RuntimeError(f"crw_rn_eval_fwd: unsupported input {tuple(x.shape)}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(P, 128, dtype=torch.float32, device=x.device)
+    _check(lib().crw_rn_eval_fwd(_dev(x, "x"), P, cin, h, w, _ptr_array(params, RN_NPARAM), _ptr_array(run_mean, RN_NBN),
+                                 _ptr_array(run_var, RN_NBN), float(eps), _dev(out, "out"), _ptr(ws), nbytes, _stream()),
+           "crw_rn_eval_fwd")
+    return out
 
 
 def rn_train_bwd(dout, x, params, ws):

@@ -212,9 +212,10 @@ struct ConvArgs {
   long long *stamps;         // diagnostic builds only: [grid][5] s_memtime at phase boundaries (else null)
   // MAP variant only: planes are feature maps [P][mh][mw][C] of any size, a workgroup computes one 10x10 output tile
   int mh, mw, tiles_x, tiles_y;
-  // ... the tiles of this launch: tile_list[0..ncls) (a launch takes the tiles of one class: full ones, or the small edge tiles)
+  // ... the tiles of this launch: tile_list[0..ncls) (a launch takes up to 64 tiles of one class: full ones, or the small edge
+  // tiles; a map with more tiles of a class than that goes out in several launches)
   int ncls;
-  unsigned char tile_list[64];
+  unsigned short tile_list[64];
 };
 
 // One workgroup = one patch, NW waves (4 or 8).  With 8 waves a wave owns one 16-channel output tile
@@ -1413,17 +1414,31 @@ int launch_conv_map_cls(const ConvArgs &a, hipStream_t s) {
   return check_launch();
 }
 
-// two launches: the tiles with more than 64 in-map pixels on 7 row tiles, the small edge tiles on 4
+// two classes of launches: the tiles with more than 64 in-map pixels on 7 row tiles, the small edge tiles on 4; a launch carries
+// the indices of at most 64 tiles in its kernel arguments, so a map with more tiles of a class (over 80 x 80 pixels, or a long
+// strip) takes one launch per 64 of them -- any map size, like the reference's convolutions
 template <int SPLIT, int CIN, int COUT, int MODE = 0>
 int launch_conv_map(const ConvArgs &a0, hipStream_t s) {
   const int ntile = a0.tiles_x * a0.tiles_y;
-  if (ntile > 64) return CRW_EINVAL;  // maps up to 80 x 80
+  if (ntile > 65535) return CRW_EINVAL;  // 16-bit tile indices: maps up to 2550 x 2550
+  constexpr int CHUNK = (int)(sizeof(a0.tile_list) / sizeof(a0.tile_list[0]));
   ConvArgs big = a0, small = a0;
   big.ncls = small.ncls = 0;
   for (int t = 0; t < ntile; ++t) {
     const int th = std::min(IMG_W, a0.mh - (t / a0.tiles_x) * IMG_W), tw = std::min(IMG_W, a0.mw - (t % a0.tiles_x) * IMG_W);
-    if (tw * th > 16 * MT_SMALL) big.tile_list[big.ncls++] = (unsigned char)t;
-    else small.tile_list[small.ncls++] = (unsigned char)t;
+    if (tw * th > 16 * MT_SMALL) {
+      big.tile_list[big.ncls++] = (unsigned short)t;
+      if (big.ncls == CHUNK) {
+        CRW_TRY((launch_conv_map_cls<SPLIT, CIN, COUT, MODE, MT>(big, s)));
+        big.ncls = 0;
+      }
+    } else {
+      small.tile_list[small.ncls++] = (unsigned short)t;
+      if (small.ncls == CHUNK) {
+        CRW_TRY((launch_conv_map_cls<SPLIT, CIN, COUT, MODE, MT_SMALL>(small, s)));
+        small.ncls = 0;
+      }
+    }
   }
   if (big.ncls) CRW_TRY((launch_conv_map_cls<SPLIT, CIN, COUT, MODE, MT>(big, s)));
   if (small.ncls) CRW_TRY((launch_conv_map_cls<SPLIT, CIN, COUT, MODE, MT_SMALL>(small, s)));

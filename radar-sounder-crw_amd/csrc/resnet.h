@@ -41,6 +41,7 @@ struct RnWgradArgs {
   int mode;                     // RN_MODE_FWD (taps of a convolution) or RN_MODE_STEM_FWD
   int Hin, Win, Cin, Hout, Wout, Cout, KH, KW, St, PAD;
   int rshift, rstride;          // r -> (r >> rshift) * rstride + (r & ((1 << rshift) - 1)); no segmentation: rshift = 30
+  int maxpair;                  // capacity of the kernel's (input pixel, output pixel) table in LDS: Hout * Wout rounded up to 64
   int ntv;                      // taps that reach the input map for at least one output pixel (the others have a zero gradient) ...
   unsigned char tapv[64];       // ... their indices; the slabs hold only these
   signed char tapinv[64];       // tap -> position in tapv, or -1
@@ -73,6 +74,8 @@ size_t rn_stem_ws_bytes();
 int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
                        const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,
                        uint16_t *m_hi, uint16_t *m_lo, float *stem, void *ws, hipStream_t s);
+int launch_rn_stem_apply(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *stem, uint16_t *m_hi,
+                         uint16_t *m_lo, hipStream_t s);
 int launch_rn_stem_stats(const float *x, int P, int cin, int h, int w, const float *w0, const float *b0, const float *gamma,
                          const float *beta, float *run_mean, float *run_var, float momentum, float eps, float *stem, void *ws,
                          hipStream_t s);
@@ -86,14 +89,26 @@ struct RnPackJob {
   const float *w;
   uint16_t *fh, *fl, *bh, *bl;
   int cout, cin, T, first_block;
+  // bcast: the source is [cout][cin] and every one of the T taps receives w * scale -- the linear head behind a global average pool
+  // over T pixels, run as ONE gathered product over the whole final map (src/encoder.py:264-266)
+  int bcast;
+  float scale;
 };
 struct RnPackJobs {
   RnPackJob job[RN_MAX_PACK_JOBS];
   int n;
 };
 int launch_rn_pack_all(RnPackJobs &jobs, hipStream_t s);
-int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, uint16_t *fh, uint16_t *fl, uint16_t *th, uint16_t *tl,
-                        hipStream_t s);
+int rn_stem_cols(int w);  // columns of the stem's input-gradient rows: 3 * (w + 2) rounded up to 64
+int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, int ncols, uint16_t *fh, uint16_t *fl, uint16_t *th,
+                        uint16_t *tl, hipStream_t s);
+// dw [cout][cin] = scale * sum over the T taps of src [cout][cin][T]
+int launch_rn_tapsum(const float *src, long n, int T, float scale, float *dw, hipStream_t s);
+// eval-mode BatchNorm: coef [4][C] (scale, shift, mean, invstd) from the running statistics; stem record from bn0's
+int launch_rn_bn_coef_eval(const float *gamma, const float *beta, const float *run_mean, const float *run_var, float eps, int C, float *coef,
+                           hipStream_t s);
+int launch_rn_stem_eval(int cin, const float *w0, const float *b0, const float *gamma, const float *beta, const float *run_mean,
+                        const float *run_var, float eps, float *stem, hipStream_t s);
 int launch_rn_split(const float *x, long rows, long rows_pad, int C, uint16_t *hi, uint16_t *lo, hipStream_t s);
 size_t rn_colsum_ws_bytes(int W);
 int launch_rn_colsum(const float *x, int R, int W, float *out, void *ws, hipStream_t s);

@@ -1,5 +1,7 @@
 // C-ABI entry points of the Resnet encoder kernels (include/crw_hip.h, "crw_rn_*"): argument checks and launch geometry.
 // Kernels: resnet_gemm.hip (matrix-core convolutions / weight gradients), resnet_bn.hip (BatchNorm, pooling, stem, packing).
+#include <algorithm>
+
 #include "resnet.h"
 
 using namespace crw;
@@ -24,14 +26,14 @@ int crw_rn_pack_conv(const float *w, int cout, int cin, int kh, int kw, uint16_t
 }
 
 int crw_rn_stem_toeplitz_ld(int w) { return w < 1 ? 0 : 4 * ((w + 1) / 2 + 1) * 64; }  // 4 kernel rows x W1 x 64
+int crw_rn_stem_cols(int w) { return w < 1 ? 0 : rn_stem_cols(w); }
 
 int crw_rn_pack_stem(const float *w1, int h, int w, uint16_t *fwd_hi, uint16_t *fwd_lo, uint16_t *toep_hi, uint16_t *toep_lo,
                      crw_stream_t stream) {
   clear_stale_error();
   if (!w1 || !fwd_hi || !fwd_lo || !toep_hi || !toep_lo || h < 1 || w < 1) return CRW_EINVAL;
   const int H0 = h + 2, W0 = w + 2, H1 = (H0 - 1) / 2 + 1, W1 = (W0 - 1) / 2 + 1;
-  if (3 * W0 > 64) return CRW_EINVAL;  // one 64-column tile holds a map row of the stem's backward-data product
-  return launch_rn_pack_stem(w1, H0, W0, H1, W1, 4 * W1 * 64, fwd_hi, fwd_lo, toep_hi, toep_lo, (hipStream_t)stream);
+  return launch_rn_pack_stem(w1, H0, W0, H1, W1, 4 * W1 * 64, rn_stem_cols(w), fwd_hi, fwd_lo, toep_hi, toep_lo, (hipStream_t)stream);
 }
 
 size_t crw_rn_conv_part_floats(int P, int G, int N) {
@@ -62,7 +64,7 @@ int rn_make_conv(RnConvArgs &a, int mode, int P, int Hs, int Ws, int Cs, int Hd,
     a.G = Hd * Wd;
     a.ldb = 256;
   } else {
-    if (Cs != 64 || kh != 7 || stride != 2 || pad != 3) return CRW_EINVAL;
+    if (Cs != 64 || kh != 7 || stride != 2 || pad != 3 || N < 3 * (2 * Ws - 1)) return CRW_EINVAL;  // N = crw_rn_stem_cols(w): a whole map row
     a.G = Hd;
     a.ldb = 4 * Ws * Cs;
     a.b_group_stride = (long)N * a.ldb;
@@ -99,6 +101,8 @@ int rn_make_wgrad(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin, in
   a.KH = kh; a.KW = kw; a.St = stride; a.PAD = pad;
   a.lda = Hin * Win * Cin;
   a.ldb = Hout * Wout * Cout;
+  a.maxpair = std::max(128, round_up(Hout * Wout, 64));
+  if (a.maxpair > 4096) return CRW_EINVAL;  // resnet_gemm.hip RN_MAXPAIR_CAP: output maps up to 64 x 64
   a.Ntot = Cout;
   a.ktiles_p = padded(P) / 64;
   if (mode == RN_MODE_FWD) {
@@ -240,11 +244,10 @@ int crw_rn_stem_fwd(const float *x, int P, int cin, int h, int w, int Hm, int Wm
 int crw_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
                     float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
-  if (!dX0 || !x || !stem || !w0 || !b0 || !dw0 || !db0 || !dgamma || !dbeta || !ws || P < 1 || cin < 1 || cin > 2 || h < 1 ||
-      3 * (w + 2) > 64)
+  if (!dX0 || !x || !stem || !w0 || !b0 || !dw0 || !db0 || !dgamma || !dbeta || !ws || P < 1 || cin < 1 || cin > 2 || h < 1 || w < 1)
     return CRW_EINVAL;
   if (ws_bytes < rn_stem_ws_bytes()) return CRW_EWORKSPACE;
-  return launch_rn_stem_bwd(dX0, x, stem, w0, b0, P, cin, h, w, 64, dw0, db0, dgamma, dbeta, ws, (hipStream_t)stream);
+  return launch_rn_stem_bwd(dX0, x, stem, w0, b0, P, cin, h, w, rn_stem_cols(w), dw0, db0, dgamma, dbeta, ws, (hipStream_t)stream);
 }
 
 /* ---- stem convolution for 16 x 16 patches, a patch per wave (resnet_stem.hip) ---- */

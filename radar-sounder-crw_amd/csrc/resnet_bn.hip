@@ -753,10 +753,10 @@ __global__ __launch_bounds__(256) void rn_pack_all_kernel(RnPackJobs jobs) {
   const RnPackJob &q = jobs.job[j];
   const int co = blockIdx.x - q.first_block;
   const int n = q.cin * q.T;
-  const float *src = q.w + (long)co * n;
+  const float *src = q.w + (long)co * (q.bcast ? q.cin : n);
   for (int e = threadIdx.x; e < n; e += 256) {
     const int ci = e / q.T, t = e - ci * q.T;
-    const float v = src[e];
+    const float v = q.bcast ? src[ci] * q.scale : src[e];
     const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
     const long f = ((long)co * q.T + t) * q.cin + ci, b = ((long)ci * q.T + t) * q.cout + co;
     q.fh[f] = h;
@@ -768,12 +768,12 @@ __global__ __launch_bounds__(256) void rn_pack_all_kernel(RnPackJobs jobs) {
 
 // stem 7x7/2 weights w1 [64][3][7][7]:
 //   forward planes [64][256]: k = ky * 32 + kx * 4 + c (zero for ky = 7, kx = 7, c = 3)
-//   Toeplitz planes [H0][64][ldt] for the backward-data GEMM: row iy, column n = ix * 3 + c (zero for n >= 3 * W0),
+//   Toeplitz planes [H0][ncols][ldt] for the backward-data GEMM (ncols = 3 * W0 rounded up to 64): row iy, column n = ix * 3 + c (zero for n >= 3 * W0),
 //     k = (oy - oy0(iy)) * (W1 * 64) + ox * 64 + co holds w1[co][c][iy + 3 - 2 oy][ix + 3 - 2 ox] (zero outside the kernel)
-__global__ __launch_bounds__(256) void rn_pack_stem_kernel(const float *__restrict__ w1, int H0, int W0, int H1, int W1, int ldt,
+__global__ __launch_bounds__(256) void rn_pack_stem_kernel(const float *__restrict__ w1, int H0, int W0, int H1, int W1, int ldt, int ncols,
                                                            uint16_t *__restrict__ fh, uint16_t *__restrict__ fl, uint16_t *__restrict__ th,
                                                            uint16_t *__restrict__ tl) {
-  const long nf = 64 * 256, nt = (long)H0 * 64 * ldt;
+  const long nf = 64 * 256, nt = (long)H0 * ncols * ldt;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nf + nt; i += (long)gridDim.x * 256) {
     float v = 0.f;
     if (i < nf) {
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void rn_pack_stem_kernel(const float *__restri
       fl[i] = f2bf(v - bf2f(h));
     } else {
       const long j = i - nf;
-      const int k = (int)(j % ldt), n = (int)((j / ldt) % 64), iy = (int)(j / ((long)ldt * 64));
+      const int k = (int)(j % ldt), n = (int)((j / ldt) % ncols), iy = (int)(j / ((long)ldt * ncols));
       int oy0 = (iy + 3 - 7 + 2) / 2;
       if (iy + 3 - 7 + 1 <= 0) oy0 = 0;
       const int co = k & 63, ox = (k >> 6) % W1, oy = oy0 + (k >> 6) / W1;
@@ -797,6 +797,46 @@ __global__ __launch_bounds__(256) void rn_pack_stem_kernel(const float *__restri
       tl[j] = f2bf(v - bf2f(h));
     }
   }
+}
+
+// dw [n] = scale * sum_t src [n][T], in tap order (the head's weight gradient behind an average pool over T pixels)
+__global__ __launch_bounds__(256) void rn_tapsum_kernel(const float *__restrict__ src, long n, int T, float scale, float *__restrict__ dw) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += src[i * T + t];
+    dw[i] = acc * scale;
+  }
+}
+
+// eval-mode BatchNorm (nn.BatchNorm2d with training = False: normalise by the RUNNING statistics, update nothing)
+__global__ __launch_bounds__(256) void rn_bn_coef_eval_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              const float *__restrict__ run_mean, const float *__restrict__ run_var, float eps,
+                                                              int C, float *__restrict__ coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double invstd = 1.0 / sqrt((double)run_var[c] + (double)eps), scale = (double)gamma[c] * invstd;
+  coef[c] = (float)scale;
+  coef[C + c] = (float)((double)beta[c] - (double)run_mean[c] * scale);
+  coef[2 * C + c] = run_mean[c];
+  coef[3 * C + c] = (float)invstd;
+}
+
+// the stem record (rn_stem_finalize_kernel's layout) from bn0's running statistics: entries [0..20]; the moments [21..26] are zero
+__global__ void rn_stem_eval_kernel(int cin, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, const float *__restrict__ run_mean, const float *__restrict__ run_var,
+                                    float eps, float *__restrict__ stem) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int c = 0; c < 3; ++c) {
+    const double invstd = 1.0 / sqrt((double)run_var[c] + (double)eps), scale = (double)gamma[c] * invstd;
+    const double shift = (double)beta[c] - (double)run_mean[c] * scale;
+    stem[c] = (float)scale;
+    stem[3 + c] = (float)shift;
+    stem[6 + c] = run_mean[c];
+    stem[9 + c] = (float)invstd;
+    for (int i = 0; i < 2; ++i) stem[12 + 2 * c + i] = i < cin ? (float)(scale * (double)w0[c * cin + i]) : 0.f;
+    stem[18 + c] = (float)(scale * (double)b0[c] + shift);
+  }
+  for (int k = 21; k < 32; ++k) stem[k] = 0.f;
 }
 
 // fp32 [rows][C] -> planes [rows_pad][C], zero rows beyond `rows`
@@ -977,6 +1017,14 @@ int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, i
   return check_launch();
 }
 
+// the map planes from a stem record that is already there (eval mode: launch_rn_stem_eval)
+int launch_rn_stem_apply(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *stem, uint16_t *m_hi,
+                         uint16_t *m_lo, hipStream_t s) {
+  const long total_px = (long)Ppad * Hm * Wm;
+  hipLaunchKernelGGL(rn_stem_apply_kernel, dim3(grid_for(total_px)), dim3(256), 0, s, x, stem, P, total_px, cin, h, w, Hm, Wm, m_hi, m_lo);
+  return check_launch();
+}
+
 int launch_rn_stem_bwd(const float *dX0, const float *x, const float *stem, const float *w0, const float *b0, int P, int cin, int h, int w,
                        int ldx, float *dw0, float *db0, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
   float *part = (float *)ws;
@@ -1012,10 +1060,29 @@ int launch_rn_pack_all(RnPackJobs &jobs, hipStream_t s) {
   return check_launch();
 }
 
-int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, uint16_t *fh, uint16_t *fl, uint16_t *th, uint16_t *tl,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(rn_pack_stem_kernel, dim3(grid_for(64 * 256 + (long)H0 * 64 * ldt)), dim3(256), 0, s, w1, H0, W0, H1, W1, ldt, fh, fl,
-                     th, tl);
+int rn_stem_cols(int w) { return round_up(3 * (w + 2), 64); }
+
+int launch_rn_pack_stem(const float *w1, int H0, int W0, int H1, int W1, int ldt, int ncols, uint16_t *fh, uint16_t *fl, uint16_t *th,
+                        uint16_t *tl, hipStream_t s) {
+  hipLaunchKernelGGL(rn_pack_stem_kernel, dim3(grid_for(64 * 256 + (long)H0 * ncols * ldt)), dim3(256), 0, s, w1, H0, W0, H1, W1, ldt, ncols,
+                     fh, fl, th, tl);
+  return check_launch();
+}
+
+int launch_rn_tapsum(const float *src, long n, int T, float scale, float *dw, hipStream_t s) {
+  hipLaunchKernelGGL(rn_tapsum_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, n, T, scale, dw);
+  return check_launch();
+}
+
+int launch_rn_bn_coef_eval(const float *gamma, const float *beta, const float *run_mean, const float *run_var, float eps, int C, float *coef,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(rn_bn_coef_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, run_mean, run_var, eps, C, coef);
+  return check_launch();
+}
+
+int launch_rn_stem_eval(int cin, const float *w0, const float *b0, const float *gamma, const float *beta, const float *run_mean,
+                        const float *run_var, float eps, float *stem, hipStream_t s) {
+  hipLaunchKernelGGL(rn_stem_eval_kernel, dim3(1), dim3(64), 0, s, cin, w0, b0, gamma, beta, run_mean, run_var, eps, stem);
   return check_launch();
 }
 

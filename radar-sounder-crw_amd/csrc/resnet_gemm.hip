@@ -602,20 +602,23 @@ int launch_conv_cfg(const RnConvArgs &a, hipStream_t s) {
 }
 
 // =============================================================================================== TN: weight gradients
-constexpr int RN_MAXPAIR = 128;
+// the (input pixel, output pixel) table of a tap lives in LDS behind the ring: 2 * maxpair ints, maxpair = the layer's output pixels
+// rounded up to 64 (RnWgradArgs::maxpair; 16 x 16 patches: at most 128 -- the stem's 81; 32 x 32: 289; the cap leaves the
+// 128 x 128 kernel its two 32 KB stages + 32 KB of table)
+constexpr int RN_MAXPAIR_CAP = 4096;
 
 template <int TM, int TN, int BK_>
 struct TNCfg {
   static constexpr int BK = BK_, WAVES = 4, FM = TM / 32, FN = TN / 32, NSTAGE = 2;
   static constexpr int IMG_A = TM * 2 * BK, IMG_B = TN * 2 * BK, STAGE = 2 * IMG_A + 2 * IMG_B;
   static constexpr int PA = TM * BK / 512 / WAVES, PB = TN * BK / 512 / WAVES;
-  static constexpr int TABLE = 2 * RN_MAXPAIR * 4 + 16;
-  static constexpr size_t LDS = (size_t)NSTAGE * STAGE + TABLE;
+  static constexpr size_t RING = (size_t)NSTAGE * STAGE;
+  static constexpr size_t lds(int maxpair) { return RING + (size_t)2 * maxpair * 4 + 16; }
 };
 
 // pairs of `tap`: pa[] = element offset of the input pixel inside an X row, pb[] = of the output pixel inside a dZ row
 __device__ inline void rn_pairs(const RnWgradArgs &a, int tap, int tid, int *pa, int *pb, int *hdr) {
-  // one wave (64 lanes), two rounds: up to 128 output pixels
+  // one wave (64 lanes), one round per 64 output pixels
   int count = 0;
   const int npix = a.Hout * a.Wout;
   for (int base = 0; base < npix; base += 64) {
@@ -650,9 +653,9 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a) {
   using C = TNCfg<TM, TN, BK_>;
   constexpr int BK = C::BK;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int *pa = reinterpret_cast<int *>(lds + C::NSTAGE * C::STAGE);
-  int *pb = pa + RN_MAXPAIR;
-  int *hdr = pb + RN_MAXPAIR;
+  int *pa = reinterpret_cast<int *>(lds + C::RING);
+  int *pb = pa + a.maxpair;
+  int *hdr = pb + a.maxpair;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mtiles = a.Mtot / TM, ntiles = a.Ntot / TN;
   // every (tap, tile) of a patch slice reads the same patches: one XCD takes whole slices, so its L2 serves the re-reads
@@ -790,14 +793,14 @@ int launch_wgrad_cfg(const RnWgradArgs &a, hipStream_t s) {
   using C = TNCfg<TM, TN, BK_>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)rn_wgrad_kernel<TM, TN, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) !=
-        hipSuccess) {
+    if (hipFuncSetAttribute((const void *)rn_wgrad_kernel<TM, TN, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::lds(RN_MAXPAIR_CAP)) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN, BK_>), dim3(a.ntv * (a.Mtot / TM) * (a.Ntot / TN) * a.S), dim3(256), C::LDS, s, a);
+  hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN, BK_>), dim3(a.ntv * (a.Mtot / TM) * (a.Ntot / TN) * a.S), dim3(256), C::lds(a.maxpair), s, a);
   return check_launch();
 }
 
@@ -844,7 +847,7 @@ int launch_rn_conv(const RnConvArgs &a, hipStream_t s) {
 int launch_rn_stem_slab_reduce(const float *slab, int nslab, float *dw, hipStream_t s) {
   RnWgradArgs a{};
   a.slab = const_cast<float *>(slab);
-  a.S = nslab; a.taps = 1; a.ntv = 1; a.Mtot = 224; a.Ntot = 64;
+  a.S = nslab; a.taps = 1; a.ntv = 1; a.Mtot = 224; a.Ntot = 64; a.maxpair = 128;
   a.tapv[0] = 0; a.tapinv[0] = 0;
   hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((224 * 64 + 63) / 64), dim3(256), 0, s, a, 1, dw);
   return check_launch();
@@ -862,7 +865,7 @@ int rn_wgrad_slices(const RnWgradArgs &a) {
 }
 
 int launch_rn_wgrad(const RnWgradArgs &a, float *dw, hipStream_t s) {
-  if (a.Mtot % 64 || a.Ntot % 64 || a.Hout * a.Wout > RN_MAXPAIR || a.S < 1) return CRW_EINVAL;
+  if (a.Mtot % 64 || a.Ntot % 64 || a.Hout * a.Wout > a.maxpair || a.maxpair > RN_MAXPAIR_CAP || a.maxpair % 64 || a.S < 1) return CRW_EINVAL;
   const bool m128 = a.Mtot % 128 == 0, n128 = a.Ntot % 128 == 0;
   static int bk = -1;
   if (bk < 0) {

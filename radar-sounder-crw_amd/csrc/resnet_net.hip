@@ -28,6 +28,8 @@ struct Wpack {
 // every buffer of a step at a fixed offset of the workspace (the same function sizes it, with base = nullptr)
 struct Plan {
   int P, Ppad, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm, ldt;
+  int ncols;        // columns of the stem's input-gradient rows (3 * W0 rounded up to 64)
+  int hl, wl, npl;  // layer4's map: the head averages over its npl pixels (src/encoder.py:264-266)
   Blk blk[4];
   char *base;
   size_t off = 0;
@@ -59,6 +61,7 @@ struct Plan {
   } r[4];
   Wpack wfc;
   float *outp;  // [Ppad][128]
+  float *dwfc;  // [128][512][npl]: the head's weight gradient per pixel of the averaged map (npl > 1)
   // scratch
   float *part, *part_d, *redpart;   // part_d / stats_ws_d: the shortcut branch computes beside the main one (side stream)
   double *stats_ws, *stats_ws_d;
@@ -87,9 +90,13 @@ struct Plan {
       b.pbase = pbase[i]; b.bn = bnidx[i];
       hh = b.hout; ww = b.wout; c = b.cout;
     }
-    // covered: patch sizes whose map is 1 x 1 at the head (the average pool is then the identity) and at most 21 columns wide
-    // (one 64-column tile per map row in the stem's backward-data product); 16 x 16, the reference's default, is the tested one
-    if (hh != 1 || ww != 1 || 3 * W0 > 64 || cin < 1 || cin > 2) ok = false;
+    // Any patch size: where layer4's map has more than one pixel (32 x 32 patches: 2 x 2) the global average pool + linear head
+    // run as ONE gathered product over the whole map -- a "convolution" whose kernel covers the map, every tap holding
+    // fc.weight / npl (RnPackJob::bcast) -- so the forward, the backward-data and the weight-gradient kernels serve it unchanged;
+    // the stem's backward-data product takes as many 64-column tiles as a map row needs.
+    hl = hh; wl = ww; npl = hh * ww;
+    ncols = rn_stem_cols(w);
+    if (cin < 1 || cin > 2 || h < 1 || w < 1 || npl > 64 || H1 * W1 > 4096) ok = false;
     if (!ok) return;
     const size_t pp = (size_t)Ppad;
     stem = take<float>(32);
@@ -100,7 +107,7 @@ struct Plan {
       stem_part = take<float>((size_t)rn_stem16_blocks() * 8 * 16);
     } else {
       wsf_h = take<uint16_t>(64 * 256); wsf_l = take<uint16_t>(64 * 256);
-      wst_h = take<uint16_t>((size_t)H0 * 64 * ldt); wst_l = take<uint16_t>((size_t)H0 * 64 * ldt);
+      wst_h = take<uint16_t>((size_t)H0 * ncols * ldt); wst_l = take<uint16_t>((size_t)H0 * ncols * ldt);
       xmap = planes(pp * Hm * Wm * 4);
     }
     Z1 = take<float>(pp * H1 * W1 * 64);
@@ -120,8 +127,9 @@ struct Plan {
       gmax = std::max(gmax, std::max(n, pp * b.hin * b.win * b.cin));
       part_max = std::max(part_max, crw_rn_conv_part_floats(P, b.hout * b.wout, b.cout));
     }
-    wfc = wpack((size_t)FEAT * 512);
+    wfc = wpack((size_t)FEAT * 512 * npl);
     outp = take<float>(pp * FEAT);
+    dwfc = npl > 1 ? take<float>((size_t)FEAT * 512 * npl) : nullptr;
     part = take<float>(part_max);
     part_d = take<float>(part_max);
     redpart = take<float>(part_max * 2);  // [rows][3][C] against [rows][C][2]
@@ -136,16 +144,19 @@ struct Plan {
     dz1 = planes(pp * H1 * W1 * 64);
     for (int i = 0; i < 2; ++i) g[i] = take<float>(gmax);
     gA = take<float>(gmax);
-    dX0 = stem16 ? nullptr : take<float>(pp * H0 * 64);
+    dX0 = stem16 ? nullptr : take<float>(pp * H0 * ncols);
     // weight-gradient slabs: the largest of any layer
-    auto need = [&](int mode, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int k, int s, int pad) {
+    auto need2 = [&](int mode, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int kh, int kw, int s, int pad) {
       RnWgradArgs a;
-      if (rn_make_wgrad(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, k, k, s, pad) != CRW_OK) { ok = false; return; }
+      if (rn_make_wgrad(a, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, s, pad) != CRW_OK) { ok = false; return; }
       wgrad_bytes = std::max(wgrad_bytes, (size_t)a.S * a.ntv * a.Mtot * a.Ntot * 4);
+    };
+    auto need = [&](int mode, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int k, int s, int pad) {
+      need2(mode, Hin, Win, Cin, Hout, Wout, Cout, k, k, s, pad);
     };
     if (stem16) wgrad_bytes = (size_t)rn_stem16_blocks() * 4 * 224 * 64 * 4;
     else need(RN_MODE_STEM_FWD, Hm, Wm, 4, H1, W1, 64, 7, 2, 3);
-    need(RN_MODE_FWD, 1, 1, 512, 1, 1, FEAT, 1, 1, 0);
+    need2(RN_MODE_FWD, hl, wl, 512, 1, 1, FEAT, hl, wl, 1, 0);
     size_t bnb = 0;
     for (int i = 0; i < 4; ++i) {
       const Blk &b = blk[i];
@@ -228,10 +239,12 @@ struct SideStream {
   }
 } g_side;
 
+// k = kh * 256 + kw for a kernel that is not square (the head over an hl x wl map), else the side
 int conv(hipStream_t s, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int k, int stride, int pad, Planes a, const uint16_t *bh,
          const uint16_t *bl, const float *bias, float *out, float *part, bool accumulate = false, const Red &red = Red()) {
   RnConvArgs q;
-  CRW_TRY(rn_make_conv(q, mode, P, Hs, Ws, Cs, Hd, Wd, N, k, k, stride, pad));
+  const int kh = k >= 256 ? k >> 8 : k, kw = k >= 256 ? k & 255 : k;
+  CRW_TRY(rn_make_conv(q, mode, P, Hs, Ws, Cs, Hd, Wd, N, kh, kw, stride, pad));
   q.a_hi = a.hi; q.a_lo = a.lo; q.b_hi = bh; q.b_lo = bl; q.out = out; q.part = part; q.bias = bias;
   q.accumulate = accumulate ? 1 : 0;
   q.red_mask = red.mask; q.red_z = red.z; q.red_coef = red.coef; q.red_zd = red.zd; q.red_coefd = red.coefd; q.red_part = red.part;
@@ -242,11 +255,132 @@ int conv(hipStream_t s, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd,
 int wgrad(hipStream_t s, int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int pad, Planes x,
           Planes d, float *dw, void *ws) {
   RnWgradArgs q;
-  CRW_TRY(rn_make_wgrad(q, mode, P, Hin, Win, Cin, Hout, Wout, Cout, k, k, stride, pad));
+  const int kh = k >= 256 ? k >> 8 : k, kw = k >= 256 ? k & 255 : k;
+  CRW_TRY(rn_make_wgrad(q, mode, P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad));
   q.x_hi = x.hi; q.x_lo = x.lo; q.d_hi = d.hi; q.d_lo = d.lo;
   q.slab = (float *)ws;
   Timed t(s, 1, mode, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad);
   return launch_rn_wgrad(q, dw, s);
+}
+
+
+// Whatever a pass has put on the side stream is joined back into the caller's stream on EVERY exit, error paths included: the caller
+// frees / re-uses the workspace and the gradient buffer in stream order of ITS stream.
+struct SideJoin {
+  hipStream_t s, sw;
+  ~SideJoin() {
+    if (sw != s && !g_side.order(sw, s)) (void)hipStreamSynchronize(sw);
+  }
+};
+
+// The forward pass.  training: BatchNorm on batch statistics (+ running-statistics update when run_mean / run_var are given);
+// otherwise (nn.Module.eval(), the reference's scripts/test/test.py:42) BatchNorm on the RUNNING statistics, nothing updated.
+int forward_pass(bool training, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
+                 float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, hipStream_t s) {
+  if (!x || !prm || !out || !ws || P < 1 || (run_mean == nullptr) != (run_var == nullptr) || (!training && !run_mean)) return CRW_EINVAL;
+  for (int i = 0; i < NPARAM; ++i)
+    if (!prm[i]) return CRW_EINVAL;
+  Plan pl(P, cin, h, w, ws);
+  if (!pl.ok) return CRW_EINVAL;
+  if (ws_bytes < pl.off) return CRW_EWORKSPACE;
+  auto rm = [&](int i) { return run_mean ? run_mean[i] : nullptr; };
+  auto rv = [&](int i) { return run_var ? run_var[i] : nullptr; };
+  // one BatchNorm's coef[4][C]: batch statistics from the producing product's per-tile partials, or the running statistics
+  auto bn_coef = [&](const float *part, int rows, int C, double cnt, const float *gamma, const float *beta, int bn, float *coef, double *sws,
+                     hipStream_t st) {
+    if (training) return launch_rn_bn_stats(part, rows, C, cnt, gamma, beta, rm(bn), rv(bn), momentum, eps, coef, sws, st);
+    return launch_rn_bn_coef_eval(gamma, beta, rm(bn), rv(bn), eps, C, coef, st);
+  };
+  // side stream: the weight packing runs beside the stem (which does not need it), each shortcut convolution + its statistics
+  // beside its block's main branch (CRW_RN_STREAMS=0: everything on the caller's stream)
+  static const bool use_side = !(getenv("CRW_RN_STREAMS") && getenv("CRW_RN_STREAMS")[0] == '0');
+  hipStream_t sw = use_side ? g_side.get() : nullptr;
+  if (!sw) sw = s;
+  g_side.used = 0;
+  auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };
+  auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };
+  SideJoin guard{s, sw};
+
+  // all convolution / linear weights -> hi / lo planes (forward and backward-data layouts), one launch
+  CRW_TRY(fork());
+  {
+    RnPackJobs jobs{};
+    auto add = [&](const float *wsrc, const Wpack &d, int cout, int cin_, int T) {
+      jobs.job[jobs.n++] = RnPackJob{wsrc, d.fh, d.fl, d.bh, d.bl, cout, cin_, T, 0};
+    };
+    for (int i = 0; i < 4; ++i) {
+      const Blk &b = pl.blk[i];
+      add(prm[b.pbase], pl.r[i].wa, b.cout, b.cin, 9);
+      add(prm[b.pbase + 3], pl.r[i].wb, b.cout, b.cout, 9);
+      if (b.down) add(prm[b.pbase + 6], pl.r[i].wd, b.cout, b.cin, 1);
+    }
+    add(prm[40], pl.wfc, FEAT, 512, pl.npl);
+    if (pl.npl > 1) {  // the head behind the average pool: every pixel of layer4's map takes fc.weight / npl
+      jobs.job[jobs.n - 1].bcast = 1;
+      jobs.job[jobs.n - 1].scale = 1.f / (float)pl.npl;
+    }
+    CRW_TRY(launch_rn_pack_all(jobs, sw));
+  }
+  // stem: fc0 + bn0 + relu0 -> 4-channel map; 7x7/2 convolution + statistics; bn1 + relu + max-pool
+  if (pl.stem16) {
+    CRW_TRY(launch_rn_pack_stem_frag(prm[4], pl.w16f, pl.w16t, s));
+    if (training) CRW_TRY(launch_rn_stem_stats(x, P, cin, h, w, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.stem, pl.stem_ws, s));
+    else CRW_TRY(launch_rn_stem_eval(cin, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), eps, pl.stem, s));
+    {
+      Timed t(s, 0, RN_MODE_STEM_FWD, 24, 24, 4, pl.H1, pl.W1, 64, 7, 2, 3);
+      CRW_TRY(launch_rn_stem16_fwd(x, P, cin, pl.stem, pl.w16f, pl.Z1, pl.part, s));
+    }
+    CRW_TRY(bn_coef(pl.part, rn_stem16_blocks() * 8, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
+  } else {
+    CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.ncols, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, s));
+    if (training) {
+      CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
+                                 pl.xmap.lo, pl.stem, pl.stem_ws, s));
+    } else {
+      CRW_TRY(launch_rn_stem_eval(cin, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), eps, pl.stem, s));
+      CRW_TRY(launch_rn_stem_apply(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, pl.stem, pl.xmap.hi, pl.xmap.lo, s));
+    }
+    CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1,
+                 training ? pl.part : nullptr));
+    CRW_TRY(bn_coef(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
+  }
+  CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, pl.amax1, s));
+
+  CRW_TRY(join());  // packed weights ready
+  Planes A = pl.A1;
+  for (int i = 0; i < 4; ++i) {
+    const Blk &b = pl.blk[i];
+    auto &r = pl.r[i];
+    const int npix = b.hout * b.wout, rows = (pl.Ppad / 128) * 2 * npix;
+    const double cnt = (double)P * npix;
+    const float *const *q = prm + b.pbase;
+    if (b.down) {  // shortcut: 1x1 / stride-2 convolution of the block input + its statistics, beside the main branch
+      CRW_TRY(fork());
+      CRW_TRY(conv(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, A, r.wd.fh, r.wd.fl, nullptr, r.Zd, training ? pl.part_d : nullptr));
+      CRW_TRY(bn_coef(pl.part_d, rows, b.cout, cnt, q[7], q[8], b.bn + 2, r.cd, pl.stats_ws_d, sw));
+    }
+    float *part = training ? pl.part : nullptr;
+    CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, A, r.wa.fh, r.wa.fl, nullptr, r.Za, part));
+    CRW_TRY(bn_coef(pl.part, rows, b.cout, cnt, q[1], q[2], b.bn, r.ca, pl.stats_ws, s));
+    CRW_TRY(launch_rn_bn_apply(r.Za, r.ca, nullptr, nullptr, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aa.hi, r.Aa.lo, s));
+    CRW_TRY(conv(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, r.wb.fh, r.wb.fl, nullptr, r.Zb, part));
+    CRW_TRY(bn_coef(pl.part, rows, b.cout, cnt, q[4], q[5], b.bn + 1, r.cb, pl.stats_ws, s));
+    if (b.down) {
+      CRW_TRY(join());
+      CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, r.Zd, r.cd, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
+    } else {
+      CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, nullptr, nullptr, A.hi, A.lo, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
+    }
+    A = r.Aout;
+  }
+  // head: global average pool + linear 512 -> 128 with bias, one product over layer4's whole map (a 1 x 1 map: the plain linear layer)
+  CRW_TRY(conv(s, RN_MODE_FWD, P, pl.hl, pl.wl, 512, 1, 1, FEAT, pl.npl > 1 ? pl.hl * 256 + pl.wl : 1, 1, 0, A, pl.wfc.fh, pl.wfc.fl, prm[41],
+               pl.outp, nullptr));
+  if (hipMemcpyAsync(out, pl.outp, (size_t)P * FEAT * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    g_last_hip_error = (int)hipGetLastError();
+    return CRW_EHIP;
+  }
+  return CRW_OK;
 }
 
 }  // namespace
@@ -262,93 +396,15 @@ size_t crw_rn_train_ws_bytes(int P, int cin, int h, int w) {
 int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
                      float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
-  if (!x || !prm || !out || !ws || P < 1 || (run_mean == nullptr) != (run_var == nullptr)) return CRW_EINVAL;
-  for (int i = 0; i < NPARAM; ++i)
-    if (!prm[i]) return CRW_EINVAL;
-  Plan pl(P, cin, h, w, ws);
-  if (!pl.ok) return CRW_EINVAL;
-  if (ws_bytes < pl.off) return CRW_EWORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  auto rm = [&](int i) { return run_mean ? run_mean[i] : nullptr; };
-  auto rv = [&](int i) { return run_var ? run_var[i] : nullptr; };
-  // side stream: the weight packing runs beside the stem (which does not need it), each shortcut convolution + its statistics
-  // beside its block's main branch (CRW_RN_STREAMS=0: everything on the caller's stream)
-  static const bool use_side = !(getenv("CRW_RN_STREAMS") && getenv("CRW_RN_STREAMS")[0] == '0');
-  hipStream_t sw = use_side ? g_side.get() : nullptr;
-  if (!sw) sw = s;
-  g_side.used = 0;
-  auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };
-  auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };
+  return forward_pass(true, x, P, cin, h, w, prm, run_mean, run_var, momentum, eps, out, ws, ws_bytes, (hipStream_t)stream);
+}
 
-  // all convolution / linear weights -> hi / lo planes (forward and backward-data layouts), one launch
-  CRW_TRY(fork());
-  {
-    RnPackJobs jobs{};
-    auto add = [&](const float *wsrc, const Wpack &d, int cout, int cin_, int T) {
-      jobs.job[jobs.n++] = RnPackJob{wsrc, d.fh, d.fl, d.bh, d.bl, cout, cin_, T, 0};
-    };
-    for (int i = 0; i < 4; ++i) {
-      const Blk &b = pl.blk[i];
-      add(prm[b.pbase], pl.r[i].wa, b.cout, b.cin, 9);
-      add(prm[b.pbase + 3], pl.r[i].wb, b.cout, b.cout, 9);
-      if (b.down) add(prm[b.pbase + 6], pl.r[i].wd, b.cout, b.cin, 1);
-    }
-    add(prm[40], pl.wfc, FEAT, 512, 1);
-    CRW_TRY(launch_rn_pack_all(jobs, sw));
-  }
-  // stem: fc0 + bn0 + relu0 -> 4-channel map; 7x7/2 convolution + statistics; bn1 + relu + max-pool
-  if (pl.stem16) {
-    CRW_TRY(launch_rn_pack_stem_frag(prm[4], pl.w16f, pl.w16t, s));
-    CRW_TRY(launch_rn_stem_stats(x, P, cin, h, w, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.stem, pl.stem_ws, s));
-    {
-      Timed t(s, 0, RN_MODE_STEM_FWD, 24, 24, 4, pl.H1, pl.W1, 64, 7, 2, 3);
-      CRW_TRY(launch_rn_stem16_fwd(x, P, cin, pl.stem, pl.w16f, pl.Z1, pl.part, s));
-    }
-    CRW_TRY(launch_rn_bn_stats(pl.part, rn_stem16_blocks() * 8, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1), momentum, eps,
-                               pl.coef1, pl.stats_ws, s));
-  } else {
-    CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, s));
-    CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
-                               pl.xmap.lo, pl.stem, pl.stem_ws, s));
-    CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1, pl.part));
-    CRW_TRY(launch_rn_bn_stats(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], rm(1), rv(1),
-                               momentum, eps, pl.coef1, pl.stats_ws, s));
-  }
-  CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, pl.amax1, s));
-
-  CRW_TRY(join());  // packed weights ready
-  Planes A = pl.A1;
-  for (int i = 0; i < 4; ++i) {
-    const Blk &b = pl.blk[i];
-    auto &r = pl.r[i];
-    const int npix = b.hout * b.wout, rows = (pl.Ppad / 128) * 2 * npix;
-    const double cnt = (double)P * npix;
-    const float *const *q = prm + b.pbase;
-    if (b.down) {  // shortcut: 1x1 / stride-2 convolution of the block input + its statistics, beside the main branch
-      CRW_TRY(fork());
-      CRW_TRY(conv(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, A, r.wd.fh, r.wd.fl, nullptr, r.Zd, pl.part_d));
-      CRW_TRY(launch_rn_bn_stats(pl.part_d, rows, b.cout, cnt, q[7], q[8], rm(b.bn + 2), rv(b.bn + 2), momentum, eps, r.cd, pl.stats_ws_d, sw));
-    }
-    CRW_TRY(conv(s, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, A, r.wa.fh, r.wa.fl, nullptr, r.Za, pl.part));
-    CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[1], q[2], rm(b.bn), rv(b.bn), momentum, eps, r.ca, pl.stats_ws, s));
-    CRW_TRY(launch_rn_bn_apply(r.Za, r.ca, nullptr, nullptr, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aa.hi, r.Aa.lo, s));
-    CRW_TRY(conv(s, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, r.wb.fh, r.wb.fl, nullptr, r.Zb, pl.part));
-    CRW_TRY(launch_rn_bn_stats(pl.part, rows, b.cout, cnt, q[4], q[5], rm(b.bn + 1), rv(b.bn + 1), momentum, eps, r.cb, pl.stats_ws, s));
-    if (b.down) {
-      CRW_TRY(join());
-      CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, r.Zd, r.cd, nullptr, nullptr, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
-    } else {
-      CRW_TRY(launch_rn_bn_apply(r.Zb, r.cb, nullptr, nullptr, A.hi, A.lo, P, pl.Ppad, npix, b.cout, 1, r.Aout.hi, r.Aout.lo, s));
-    }
-    A = r.Aout;
-  }
-  // head: the average pool of the 1 x 1 map is the identity; linear 512 -> 128 with bias
-  CRW_TRY(conv(s, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, A, pl.wfc.fh, pl.wfc.fl, prm[41], pl.outp, nullptr));
-  if (hipMemcpyAsync(out, pl.outp, (size_t)P * FEAT * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-    g_last_hip_error = (int)hipGetLastError();
-    return CRW_EHIP;
-  }
-  return CRW_OK;
+int crw_rn_eval_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, const float *const *run_mean,
+                    const float *const *run_var, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  return forward_pass(false, x, P, cin, h, w, prm, const_cast<float *const *>(reinterpret_cast<const float *const *>(run_mean)),
+                      const_cast<float *const *>(reinterpret_cast<const float *const *>(run_var)), 0.f, eps, out, ws, ws_bytes,
+                      (hipStream_t)stream);
 }
 
 int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *grads,
@@ -367,11 +423,14 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   if (!sw) sw = s;
   g_side.used = 0;
   auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };  // side stream sees what the chain has produced
+  SideJoin guard{s, sw};  // error paths included: the caller's stream waits for whatever the side stream still holds
 
-  // head
+  // head (one product over layer4's hl x wl map, see Plan): per-pixel weight gradients, then their mean = fc.weight's gradient
+  const int khead = pl.npl > 1 ? pl.hl * 256 + pl.wl : 1;
   CRW_TRY(launch_rn_split(dout, P, pl.Ppad, FEAT, pl.dO.hi, pl.dO.lo, s));
   CRW_TRY(fork());
-  CRW_TRY(wgrad(sw, RN_MODE_FWD, P, 1, 1, 512, 1, 1, FEAT, 1, 1, 0, pl.r[3].Aout, pl.dO, grads[40], pl.wgrad_ws));
+  CRW_TRY(wgrad(sw, RN_MODE_FWD, P, pl.hl, pl.wl, 512, 1, 1, FEAT, khead, 1, 0, pl.r[3].Aout, pl.dO, pl.npl > 1 ? pl.dwfc : grads[40], pl.wgrad_ws));
+  if (pl.npl > 1) CRW_TRY(launch_rn_tapsum(pl.dwfc, (long)FEAT * 512, pl.npl, 1.f / (float)pl.npl, grads[40], sw));
   CRW_TRY(launch_rn_colsum(dout, P, FEAT, grads[41], pl.colsum_ws, s));
   // Gradients meet at every block output (main branch + shortcut): the first product writes, the second ADDS in its epilogue.
   // The product that completes a gradient also takes the BatchNorm-backward sums of the layer it feeds in its epilogue
@@ -383,7 +442,7 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   float *g = pl.g[0];                   // gradient of the current block's output
   {
     const auto &r3 = pl.r[3];
-    CRW_TRY(conv(s, RN_MODE_BWD, P, 1, 1, FEAT, 1, 1, 512, 1, 1, 0, pl.dO, pl.wfc.bh, pl.wfc.bl, nullptr, g, nullptr, false,
+    CRW_TRY(conv(s, RN_MODE_BWD, P, 1, 1, FEAT, pl.hl, pl.wl, 512, khead, 1, 0, pl.dO, pl.wfc.bh, pl.wfc.bl, nullptr, g, nullptr, false,
                  fuse_red ? Red{r3.Aout.hi, r3.Zb, r3.cb, r3.Zd, r3.cd, pl.redpart} : Red()));
   }
   for (int i = 3; i >= 0; --i) {
@@ -439,8 +498,8 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   }
   CRW_TRY(join());
   CRW_TRY(wgrad(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.dz1, grads[4], pl.wgrad_ws));
-  CRW_TRY(conv(s, RN_MODE_STEM_BWD, P, pl.H1, pl.W1, 64, pl.H0, 1, 64, 7, 2, 3, pl.dz1, pl.wst_h, pl.wst_l, nullptr, pl.dX0, nullptr));
-  CRW_TRY(launch_rn_stem_bwd(pl.dX0, x, pl.stem, prm[0], prm[1], P, cin, h, w, 64, grads[0], grads[1], grads[2], grads[3], pl.stem_ws, s));
+  CRW_TRY(conv(s, RN_MODE_STEM_BWD, P, pl.H1, pl.W1, 64, pl.H0, 1, pl.ncols, 7, 2, 3, pl.dz1, pl.wst_h, pl.wst_l, nullptr, pl.dX0, nullptr));
+  CRW_TRY(launch_rn_stem_bwd(pl.dX0, x, pl.stem, prm[0], prm[1], P, cin, h, w, pl.ncols, grads[0], grads[1], grads[2], grads[3], pl.stem_ws, s));
   return CRW_OK;
 }
 

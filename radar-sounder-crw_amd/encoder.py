@@ -272,10 +272,12 @@ class _ResNetBody(nn.Module):
 class Resnet(nn.Module):
     """1x1 conv (padding 1) + BN + ReLU lifting 1-2 channels to 3, then the ResNet body.
 
-    On an MI355X, for 16x16 fp32 patches in train mode (the only mode the reference runs: it never calls ``.eval()``, so its
-    BatchNorms always use batch statistics), forward AND backward run on the hand-written HIP kernels (``resnet_hip``: every
-    convolution as a matrix-core product across patches, BatchNorm statistics from the convolutions' epilogues); ``hip_convs =
-    None`` selects the PyTorch ops, which also serve CPU tensors (host tests).  A CUDA batch that misses the HIP path warns once."""
+    On an MI355X, fp32 patches of any size run on the hand-written HIP kernels (``resnet_hip``: every convolution as a matrix-core
+    product across patches, BatchNorm statistics from the convolutions' epilogues): in train mode (scripts/train.py, and the test
+    scripts that never call ``.eval()``: BatchNorm on batch statistics) forward AND backward; in eval mode (scripts/test/test.py:42
+    ``encoder.train(False)``: BatchNorm on the running statistics) the forward under ``torch.no_grad()``.  ``hip_convs = None``
+    selects the PyTorch ops, which also serve CPU tensors (host tests).  A CUDA batch that misses the HIP path (``resnet_hip.
+    supported``) warns once."""
     _warned_fallback = False
 
     def __init__(self, pos_embed=True, pretrained=None):  # `pretrained` is ignored by the reference too
@@ -293,11 +295,14 @@ class Resnet(nn.Module):
         if self.hip_convs and x.is_cuda:
             import resnet_hip
             if resnet_hip.supported(x, self):
+                if not self.training:
+                    return resnet_hip.eval_forward(x, self)
                 fn = resnet_hip.HipResnetFn if self.hip_convs == "stepwise" else resnet_hip.HipResnetNative
                 return fn.apply(x, self, *self.parameters())
             if not Resnet._warned_fallback:
                 Resnet._warned_fallback = True
-                warnings.warn(f"Resnet.forward: input {tuple(x.shape)} {x.dtype} (training: {self.training}) is not covered by the HIP "
-                              "kernels (float32 16x16 patches in train mode on an MI355X): this call runs on PyTorch-ROCm / MIOpen",
-                              RuntimeWarning, stacklevel=2)
+                warnings.warn(f"Resnet.forward: input {tuple(x.shape)} {x.dtype} (training: {self.training}, grad enabled: "
+                              f"{torch.is_grad_enabled()}) is not covered by the HIP kernels (resnet_hip.supported: float32 patches on "
+                              "an MI355X, train mode, or eval mode under no_grad, uniform BatchNorms): this call runs on PyTorch-ROCm / "
+                              "MIOpen", RuntimeWarning, stacklevel=2)
         return self.model(self.relu0(self.bn0(self.fc0(x))))

@@ -25,6 +25,7 @@ Label maps are upsampled to pixels with nearest-neighbour interpolation like the
 import torch
 import torch.nn.functional as TF
 
+import crw_hip
 from utils import propagate
 
 
@@ -89,11 +90,14 @@ def segment(dataset, seg, encoder, lp, nclasses, seq_length, patch_size, overlap
                 seg_ref = seg[:, rg_len * t + rg_len - px:rg_len * t + rg_len - px + W]
                 pred, _, _ = propagate(seq, seg_ref, encoder, lp, nclasses, pos_embed, use_last=False)
                 maps[t][:, rg_len - px:] = _upsample(pred, rows, px)
-            except RuntimeError as e:
-                # ... but a failure of the HIP path (crw_hip._check: launch failure, workspace, GPU fault) or of the device is not
-                # a data problem: the reference's bare `except` would hide a poisoned device context behind an uncorrected map
-                if "failed: CRW_" in str(e) or "HIP" in str(e) or "hip" in str(e) or "CUDA" in str(e):
+            except crw_hip.CrwError as e:
+                # ... but a failure of the HIP path itself (CRW_EHIP: launch failure / GPU fault, CRW_EWORKSPACE) is not a data
+                # problem: the reference's bare `except` would hide a poisoned device context behind an uncorrected map.
+                # CRW_EINVAL (a degenerate correction window: bad shape / unsupported size) IS the data and is skipped
+                if e.device_failure:
                     raise
+            except torch.AcceleratorError:  # the device runtime's own errors (hipError* raised by PyTorch)
+                raise
             except Exception:
                 pass
 

@@ -1,8 +1,16 @@
 """``Resnet`` (the reference's default encoder, src/encoder.py:63-89 / :109-155 / :157-272) forward AND backward on the
 hand-written HIP kernels of csrc/resnet_gemm.hip + csrc/resnet_bn.hip, through the C ABI (``crw_rn_*``).
 
+Covered: float32 patches of ANY size on the GPU.  Train mode (``module.train()``: what scripts/train.py and most of the reference's
+test scripts run -- they never call ``.eval()``): forward and backward, BatchNorm on batch statistics with the running-statistics
+update.  Eval mode (``module.eval()`` / ``train(False)``: scripts/test/test.py:42): the forward on the running statistics under
+``torch.no_grad()``.  Not covered (PyTorch ops, with a one-time warning): an eval-mode forward that autograd must differentiate,
+BatchNorms that are individually frozen or differ in eps / momentum, ``momentum=None``.
+
 Schedule of one training step for 16x16 patches (P patches; every convolution is a matrix product across patches, every
-BatchNorm runs on batch statistics exactly like ``nn.BatchNorm2d`` in train mode and updates its running statistics):
+BatchNorm runs on batch statistics exactly like ``nn.BatchNorm2d`` in train mode and updates its running statistics; other patch
+sizes: the stem on the gathered products instead of the patch-per-wave kernels, and where layer4's map keeps more than one pixel
+-- 32x32 patches: 2x2 -- the average pool + head as one product over that map):
 
     stem     bn0 statistics from the moments of x; fc0 + bn0 + relu0 + 7x7/2 convolution, a patch per wave (the 3-channel map
              lives in LDS only) -> Z1 [P,81,64] + statistics                                 crw_rn_stem_stats, crw_rn_stem16_fwd, crw_rn_bn_stats_rows
@@ -19,21 +27,44 @@ import torch
 import crw_hip as H
 
 
+def _out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def final_map(h, w):
+    """layer4's map for h x w patches: 1x1 conv with padding 1, 7x7/2, max-pool 3x3/2, strides 1, 2, 2, 2"""
+    hh, ww = _out(_out(h + 2, 7, 2, 3), 3, 2, 1), _out(_out(w + 2, 7, 2, 3), 3, 2, 1)
+    for _ in range(3):
+        hh, ww = _out(hh, 3, 2, 1), _out(ww, 3, 2, 1)
+    return hh, ww
+
+
 def supported(x, net):
-    """the HIP path covers fp32 16x16 patches on the GPU in train mode (the reference never calls .eval())"""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(x.shape[-2:]) == (16, 16) and x.shape[1] in (1, 2)
-            and net.training and net.bn0.momentum is not None)
+    """What the HIP path covers (module docstring).  Everything the native pass assumes about the module is checked here: the input
+    channels fc0 was built for (a mismatch must reach PyTorch's shape error, not an out-of-bounds read of fc0.weight), ONE mode, eps
+    and momentum for all 13 BatchNorms (the C ABI takes one of each), a final map the head product can cover."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == net.fc0.in_channels and x.shape[1] in (1, 2)):
+        return False
+    if net.fc0.weight.dtype != torch.float32:
+        return False
+    hl, wl = final_map(*x.shape[-2:])
+    if hl * wl > 64 or _out(x.shape[-2] + 2, 7, 2, 3) * _out(x.shape[-1] + 2, 7, 2, 3) > 4096:
+        return False
+    bns = _bn_modules(net)
+    if len(bns) != H.RN_NBN or any(m.training != net.training or m.eps != net.bn0.eps or m.momentum != net.bn0.momentum
+                                   or not m.track_running_stats or not m.affine for m in bns):
+        return False
+    if net.training:
+        return net.bn0.momentum is not None
+    return not torch.is_grad_enabled()  # eval mode: the forward only
 
 
 def check_batch(x):
     """nn.BatchNorm2d refuses a training batch with ONE value per channel (torch.nn.functional._verify_batch_size): layer4's map is
     1 x 1 at 16x16 patches, so a single patch raises there in the reference -- same error here, before any launch."""
-    if x.shape[0] == 1:
+    hl, wl = final_map(*x.shape[-2:])
+    if x.shape[0] * hl * wl == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([1, 512, 1, 1])}")
-
-
-def _out(n, k, s, p):
-    return (n + 2 * p - k) // s + 1
 
 
 class _Block:
@@ -61,7 +92,7 @@ class HipResnetNative(torch.autograd.Function):
         check_batch(x)
         x = x.contiguous()
         bns = _bn_modules(net)
-        prm = [p.detach() for p in params]
+        prm = [p.detach().contiguous() for p in params]
         out, ws = H.rn_train_fwd(x, prm, [m.running_mean for m in bns], [m.running_var for m in bns], net.bn0.momentum, net.bn0.eps)
         torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         ctx.x, ctx.ws, ctx.prm = x, ws, prm
@@ -74,6 +105,13 @@ class HipResnetNative(torch.autograd.Function):
         grads = H.rn_train_bwd(dout.contiguous().float(), ctx.x, ctx.prm, ctx.ws)
         ctx.ws = None
         return (None, None) + tuple(grads)
+
+
+def eval_forward(x, net):
+    """``net.eval()`` under ``torch.no_grad()``: the same launches with every BatchNorm on its running statistics (crw_rn_eval_fwd)"""
+    bns = _bn_modules(net)
+    return H.rn_eval_fwd(x.contiguous(), [p.detach().contiguous() for p in net.parameters()], [m.running_mean for m in bns],
+                         [m.running_var for m in bns], net.bn0.eps)
 
 
 class HipResnetFn(torch.autograd.Function):
@@ -93,9 +131,8 @@ class HipResnetFn(torch.autograd.Function):
             b = _Block(getattr(body, f"layer{i}")[0], hh, ww)
             blocks.append(b)
             hh, ww = b.hout, b.wout
-        if (hh, ww) != (1, 1):
-            raise RuntimeError(f"HIP Resnet path: unsupported patch size {h}x{w}")
-        sv = {"geo": (P, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm), "x": x, "blocks": blocks}
+        hl, wl = hh, ww  # layer4's map: the head averages over it (src/encoder.py:264-266)
+        sv = {"geo": (P, cin, h, w, H0, W0, H1, W1, H2, W2, Hm, Wm), "x": x, "blocks": blocks, "head": (hl, wl)}
 
         # ---- stem: 16 x 16 patches on the patch-per-wave kernels (no map in HBM), other sizes on the gathered product
         if (h, w) == (16, 16):
@@ -138,9 +175,11 @@ class HipResnetFn(torch.autograd.Function):
             r["Aout"] = A
             recs.append(r)
 
-        # ---- head (the average pool of a 1x1 map is the identity)
-        wfc = H.rn_pack_conv(body.fc.weight)
-        out, _ = H.rn_conv(H.RN_FWD, P, (1, 1, 512), (1, 1), body.fc.out_features, (1, 1), 1, 0, A, wfc[:2], bias=body.fc.bias.detach())
+        # ---- head: global average pool + linear layer as ONE product over layer4's map -- a "convolution" whose kernel covers the
+        # map, every tap holding fc.weight / npix (the average pool of a 1x1 map is the identity: the plain linear layer)
+        wrep = (body.fc.weight.detach() / (hl * wl))[:, :, None, None].expand(-1, -1, hl, wl).contiguous()
+        wfc = H.rn_pack_conv(wrep)
+        out, _ = H.rn_conv(H.RN_FWD, P, (hl, wl, 512), (1, 1), body.fc.out_features, (hl, wl), 1, 0, A, wfc[:2], bias=body.fc.bias.detach())
         sv.update(recs=recs, wfc=wfc, Alast=A)
         bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
         torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
@@ -160,9 +199,11 @@ class HipResnetFn(torch.autograd.Function):
         dout = dout.contiguous().float()
         dO = H.rn_split(dout, P, dout.shape[1])
         nout = dout.shape[1]
-        grads["model.fc.weight"] = H.rn_wgrad(H.RN_FWD, P, (1, 1, 512), (1, 1, nout), (1, 1), 1, 0, sv["Alast"], dO).reshape(nout, 512)
+        hl, wl = sv["head"]
+        dwrep = H.rn_wgrad(H.RN_FWD, P, (hl, wl, 512), (1, 1, nout), (hl, wl), 1, 0, sv["Alast"], dO)  # per pixel of the averaged map
+        grads["model.fc.weight"] = dwrep.reshape(nout, 512, hl * wl).sum(-1) / (hl * wl)
         grads["model.fc.bias"] = H.rn_colsum(dout)
-        g1, _ = H.rn_conv(H.RN_BWD, P, (1, 1, nout), (1, 1), 512, (1, 1), 1, 0, dO, sv["wfc"][2:])
+        g1, _ = H.rn_conv(H.RN_BWD, P, (1, 1, nout), (hl, wl), 512, (hl, wl), 1, 0, dO, sv["wfc"][2:])
         g2 = None
         for i in (3, 2, 1, 0):
             b, r = sv["blocks"][i], sv["recs"][i]
@@ -196,7 +237,7 @@ class HipResnetFn(torch.autograd.Function):
             dw0, db0, dg, db = H.rn_stem16_bwd(sv["x"], sv["stem"], net.fc0.weight.detach(), net.fc0.bias.detach(), sv["wstem"][1], dz1)
         else:
             grads["model.conv1.weight"] = H.rn_wgrad(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1, 64), (7, 7), 2, 3, sv["xmap"], dz1)
-            dX0, _ = H.rn_conv(H.RN_STEM_BWD, P, (H1, W1, 64), (H0, 1), 64, (7, 7), 2, 3, dz1, sv["wstem"][2:])
+            dX0, _ = H.rn_conv(H.RN_STEM_BWD, P, (H1, W1, 64), (H0, 1), H.rn_stem_cols(w), (7, 7), 2, 3, dz1, sv["wstem"][2:])
             dw0, db0, dg, db = H.rn_stem_bwd(dX0, sv["x"], sv["stem"], net.fc0.weight.detach(), net.fc0.bias.detach())
         grads["fc0.weight"], grads["fc0.bias"], grads["bn0.weight"], grads["bn0.bias"] = dw0, db0, dg, db
         ctx.sv = None

@@ -358,16 +358,19 @@ def run_segment_case(ref_dataset, name, dataset_id, nclasses, T, hw, oh, H_rg, n
           f"pixels changed by the reverse merge={changed}")
 
 
-def run_resnet_train_case(ref_model, ref_encoder, name, B, T, N, tau, seed):
+def run_resnet_train_case(ref_model, ref_encoder, name, B, T, N, tau, seed, hw=(16, 16), oh=8, eval_after=False):
     """Reference CRW with its default encoder (Resnet, BatchNorm in train mode) on CPU: loss, A, features, a selection of
-    parameter gradients (+ the norm of every gradient) and the BatchNorm running statistics after the step."""
+    parameter gradients (+ the norm of every gradient) and the BatchNorm running statistics after the step.  `hw` / `oh`: patch
+    size and vertical overlap (32 x 32 / 24: scripts/test/test_mc1.py:19,21).  eval_after: also the features of the same patches
+    from the encoder switched to eval mode after the step (`encoder.train(False)`, scripts/test/test.py:42: BatchNorm on the
+    running statistics the step has just updated) and EVERY running statistic."""
     torch.manual_seed(seed)
     enc = ref_encoder.Resnet(False)
     enc.train(True)
     gen = torch.Generator().manual_seed(seed)
-    oh = 8
-    rg = layered_radargram(N * 8 + oh, 2 * T * 16, gen)
-    seq = torch.stack([unfold_items(rg, T, 16, 16, oh, 0, i * T) for i in range(B)])
+    h, w = hw
+    rg = layered_radargram(N * (h - oh) + oh, 2 * T * w, gen)
+    seq = torch.stack([unfold_items(rg, T, h, w, oh, 0, i * T) for i in range(B)])
     crw = ref_model.CRW(enc, tau, False)
     feats = {}
     hook = enc.register_forward_hook(lambda m, i, o: feats.__setitem__("emb", o.detach().clone()))
@@ -390,9 +393,15 @@ def run_resnet_train_case(ref_model, ref_encoder, name, B, T, N, tau, seed):
     out["bn0.running_mean"] = enc.bn0.running_mean.numpy()
     out["bn0.running_var"] = enc.bn0.running_var.numpy()
     out["model.bn1.running_mean"] = enc.model.bn1.running_mean.numpy()
+    if eval_after:
+        enc.train(False)
+        with torch.no_grad():
+            out["emb_eval"] = enc(seq.reshape(-1, 1, h, w)).numpy()
+        for k, b in enc.named_buffers():
+            if b.is_floating_point():
+                out["buffer." + k] = b.numpy()
     np.savez(os.path.join(HERE, name + ".npz"), **out)
     print(f"{name}: loss={float(loss):.7f} seq{tuple(seq.shape)} {len(names)} parameter tensors")
-
 
 
 def run_dataset_case(ref_dataset, name, H, W, length, dim, overlap, seed):
@@ -428,6 +437,15 @@ def run_resnet_case(ref_encoder, name, seed):
 def main():
     torch.set_num_threads(8)
     ref_model, ref_encoder, ref_utils, ref_dataset, ref_lp = import_reference()
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]  # --only=<fixture name prefix>: just those cases
+    if only:
+        g = globals()
+        for fn in [k for k in g if k.startswith("run_") and k.endswith("_case")]:
+            def gated(*a, _f=g[fn], **k):
+                name = next(v for v in a if isinstance(v, str))
+                if any(name.startswith(o) for o in only):
+                    _f(*a, **k)
+            g[fn] = gated
     # walk on fixed features: shapes of BASELINE configs 1-3 plus odd/edge cases
     run_walk_case(ref_model, "walk_cfg1_B2T8N7", 2, 8, 7, 128, 0.01, 0.25, 11)
     run_walk_case(ref_model, "walk_odd_B1T4N5", 1, 4, 5, 16, 0.1, 0.5, 12)
@@ -452,6 +470,10 @@ def main():
                        dict(CXT_SIZE=80, RADIUS=10, TEMP=0.01, KNN=10), False, 34)
     run_resnet_case(ref_encoder, "resnet_seed11", 11)
     run_resnet_train_case(ref_model, ref_encoder, "resnet_train_B2T4N5", 2, 4, 5, 0.05, 11)
+    # the reference's cfg5-shaped encoder input: 32 x 32 patches, overlap (24, 0) (scripts/test/test_mc1.py:19,21) -- layer4's map is
+    # 2 x 2 there, so the global average pool is no longer the identity; and a non-square size whose stem rows need two column tiles
+    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_32x32_B2T3N4", 2, 3, 4, 0.05, 12, hw=(32, 32), oh=24, eval_after=True)
+    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_20x27_B1T3N5", 1, 3, 5, 0.05, 13, hw=(20, 27), oh=10)
     # whole-radargram pipeline through the reference's own driver (scripts/test/test_all.py main)
     lpc = dict(CXT_SIZE=4, RADIUS=4, TEMP=0.1, KNN=5)
     run_segment_case(ref_dataset, "segment_ds0_reverse", 0, 4, 8, (8, 8), 4, 52, 3, 2, lpc, True, False, None, 51)

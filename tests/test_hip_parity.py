@@ -342,6 +342,38 @@ def test_encoder_inference_trunk_any_patch_size(hip, hw, split):
         torch.testing.assert_close((yh.float() + yl.float()).cpu().double(), y_ref, rtol=5e-5, atol=5e-5)
 
 
+@pytest.mark.parametrize("hw", [(96, 96), (12, 706), (100, 73)])
+def test_map_convolutions_beyond_64_tiles(hip, hw):
+    """Feature maps with more than 64 tiles of a class (a map launch names at most 64 tiles in its kernel arguments; larger maps
+    go out in chunks): 96x96 patches = 81 full tiles, a 12x706 strip = 70 small edge tiles (6x10 pixels), 100x73 = 10x7 tiles with
+    7 + 10 - 1 partial ones on the edges -- inference and a training step (forward, backward-data, weight gradients, front end) of
+    the whole CNN against the same network in fp64; the reference's convolutions take any patch size (src/encoder.py:13-32)."""
+    import warnings
+    import encoder as crw_encoder
+    torch.manual_seed(7)
+    enc = crw_encoder.CNN(False)
+    enc64 = crw_encoder.CNN(False).double()
+    enc64.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
+    enc64.hip_convs = None
+    g = torch.Generator().manual_seed(hw[0])
+    x = torch.randn(2, 1, *hw, generator=g)
+    gy = torch.randn(2, 128, generator=g)
+    want = enc64(x.double())
+    want.backward(gy.double())
+    enc = enc.cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the PyTorch-op fallback would warn: it must not be taken
+        with torch.no_grad():
+            got_inf = enc(x.cuda())
+        got = enc(x.cuda())
+        got.backward(gy.cuda())
+    torch.testing.assert_close(got_inf.cpu().double(), want.detach(), rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(got.detach().cpu().double(), want.detach(), rtol=2e-4, atol=2e-5)
+    for (k, p_), (_, q) in zip(enc.named_parameters(), enc64.named_parameters()):
+        ref = q.grad
+        torch.testing.assert_close(p_.grad.cpu().double(), ref, rtol=2e-2, atol=2e-3 * ref.abs().max().item(), msg=lambda m: f"{k}: {m}")
+
+
 @pytest.mark.parametrize("hw,ov", [((32, 32), (24, 0)), ((20, 27), (10, 0))])
 def test_training_at_other_patch_sizes_vs_oracle(hip, hw, ov):
     """Training step at patch sizes other than 16x16 (BASELINE config 5 is a 32x32-patch model, overlap (24,0),

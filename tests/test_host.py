@@ -304,11 +304,52 @@ def test_segment_driver_matches_reference_main(name):
         assert any(f >= 0 for f in g["forced_change"])
 
 
-def test_resnet_train_mode_matches_reference_on_cpu():
+@pytest.mark.parametrize("status,raises", [(1, False), (2, True), (3, True)])
+def test_correction_step_error_policy(status, raises):
+    """A correction that fails on its DATA is skipped like the reference's bare `except` does (scripts/test/test_all.py:113-122) --
+    that includes CRW_EINVAL from the C ABI (a degenerate correction window) and ordinary Python errors; a failure of the HIP path
+    itself (CRW_EWORKSPACE / CRW_EHIP, typed `crw_hip.CrwError`) aborts the segmentation."""
+    import crw_hip
+    g = load_golden("segment_ds0_correction")
+    calls = {"n": 0}
+    n_items = sum(1 for _ in g["forced_change"])
+
+    def propagate(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last):
+        T, N = seq.shape[:2]
+        calls["n"] += 1
+        if calls["n"] > n_items:  # the correction calls come after one forward call per item
+            raise crw_hip.CrwError("crw_labelprop_topk", status, 0)
+        return torch.zeros(N, T), torch.zeros(N, T - 1), None
+
+    if raises:
+        with pytest.raises(crw_hip.CrwError) as e:
+            run_segment_golden(g, propagate, "cpu")
+        assert e.value.status == status and e.value.device_failure
+    else:
+        out = run_segment_golden(g, propagate, "cpu")
+        assert calls["n"] > n_items and not out["forward"].any()  # the correction ran, failed on its data and was skipped
+
+    def broken(seq, seg_ref, model, lp, ncls, do_pos_embed, use_last):
+        calls["n"] += 1
+        if calls["n"] > n_items:
+            raise IndexError("a data error inside the correction")
+        return torch.zeros(seq.shape[1], seq.shape[0]), torch.zeros(seq.shape[1], seq.shape[0] - 1), None
+
+    calls["n"] = 0
+    run_segment_golden(g, broken, "cpu")
+
+
+RESNET_TRAIN_CASES = ["resnet_train_B2T4N5", "resnet_train_32x32_B2T3N4", "resnet_train_20x27_B1T3N5"]
+
+
+@pytest.mark.parametrize("name", RESNET_TRAIN_CASES)
+def test_resnet_train_mode_matches_reference_on_cpu(name):
     """`Resnet` (the reference's default encoder) in train mode: features, BatchNorm running statistics and -- through the
-    oracle's walk -- loss and parameter gradients against the reference's CRW forward/backward (fixture resnet_train_*)."""
+    oracle's walk -- loss and parameter gradients against the reference's CRW forward/backward (fixture resnet_train_*: 16x16
+    patches; 32x32 with overlap 24 -- scripts/test/test_mc1.py:19,21, layer4's map 2x2 --; 20x27); then, where the fixture has it,
+    the encoder switched to eval mode after the step (scripts/test/test.py:42) against the reference's eval features."""
     import encoder as crw_encoder
-    g = load_golden("resnet_train_B2T4N5")
+    g = load_golden(name)
     torch.manual_seed(int(g["seed"]))
     enc = crw_encoder.Resnet(False)
     enc.train(True)
@@ -329,3 +370,49 @@ def test_resnet_train_mode_matches_reference_on_cpu():
         if "grad." + k in g:
             ref = g["grad." + k]
             np.testing.assert_allclose(p.grad.numpy(), ref, rtol=5e-3, atol=5e-4 * np.abs(ref).max())
+    if "emb_eval" in g:
+        enc.train(False)
+        with torch.no_grad():
+            emb_eval = enc(seq.reshape(-1, h, w).unsqueeze(1))
+        np.testing.assert_allclose(emb_eval.numpy(), g["emb_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_resnet_hip_coverage_rule():
+    """`resnet_hip.supported` (what may take the HIP kernels) as a pure function of module and input: checked with a stand-in for
+    a device tensor, no GPU involved."""
+    import encoder as crw_encoder
+    import resnet_hip
+
+    class X:  # the attributes `supported` reads
+        is_cuda, dtype = True, torch.float32
+
+        def __init__(self, *shape):
+            self.shape = torch.Size(shape)
+
+        def dim(self):
+            return len(self.shape)
+
+    net = crw_encoder.Resnet(False)
+    ok = lambda x, n=net: resnet_hip.supported(x, n)
+    assert resnet_hip.final_map(16, 16) == (1, 1) and resnet_hip.final_map(32, 32) == (2, 2) and resnet_hip.final_map(20, 27) == (1, 1)
+    assert resnet_hip.final_map(64, 64) == (3, 3)
+    net.train(True)
+    assert ok(X(4, 1, 16, 16)) and ok(X(4, 1, 32, 32)) and ok(X(4, 1, 20, 27)) and ok(X(2, 1, 96, 40))
+    assert not ok(X(4, 2, 16, 16))              # fc0 was built for one channel: PyTorch's shape error, not an out-of-bounds read
+    assert resnet_hip.supported(X(4, 2, 16, 16), crw_encoder.Resnet(True))
+    x64 = X(4, 1, 16, 16)
+    x64.dtype = torch.float64
+    assert not ok(x64)
+    net.train(False)                             # eval mode: the forward only
+    with torch.no_grad():
+        assert ok(X(4, 1, 16, 16)) and ok(X(4, 1, 32, 32))
+    assert not ok(X(4, 1, 16, 16))               # (grad enabled)
+    net.train(True)
+    net.model.layer3[0].bn2.eval()               # one frozen BatchNorm: the native pass has one mode for all of them
+    assert not ok(X(4, 1, 16, 16))
+    net.train(True)
+    net.model.layer2[0].bn1.eps = 1e-3           # ... and one eps / momentum
+    assert not ok(X(4, 1, 16, 16))
+    net.model.layer2[0].bn1.eps = net.bn0.eps
+    net.bn0.momentum = None                      # cumulative moving average: not implemented
+    assert not ok(X(4, 1, 16, 16))

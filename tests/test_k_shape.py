@@ -79,19 +79,23 @@ def _walk_reference_fp64(emb, tau):
     return loss.item(), A.detach(), torch.stack(Ats, 1), e64.grad
 
 
-# tolerances per chain arithmetic: (At rtol, At atol as a fraction of max|At|, loss, gradient rtol, gradient atol fraction)
+# tolerances per chain arithmetic: (At rtol, At atol as a fraction of max|At|, loss, gradient rtol, gradient atol as a fraction of
+# max|gradient|).  Measured on the box (T = 6): f32 8.5e-5 of the At bound, gradient 1.9e-5 of its maximum; bf16x3 3.7e-5 / 1.7e-5;
+# bf16 1.3e-2 / 2.7e-3; |loss - fp64| 2e-10 / 7e-10 / 8e-7
 _TOL = {0: (1e-4, 1e-6, 1e-4, 2e-3, 1e-3),      # CRW_CHAIN_F32: the parity bar
-        2: (2e-4, 2e-6, 1e-4, 2e-2, 2e-3),      # CRW_CHAIN_BF16X3: hi/lo pairs, fp32-grade
-        1: (3e-2, 2e-3, 5e-3, 6e-1, 6e-2)}      # CRW_CHAIN_BF16: plain bf16 probabilities, the throughput mode
+        2: (2e-4, 2e-6, 1e-4, 2e-3, 1e-3),      # CRW_CHAIN_BF16X3: hi/lo pairs, fp32-grade
+        1: (3e-2, 2e-3, 1e-4, 5e-2, 1e-2)}      # CRW_CHAIN_BF16: plain bf16 probabilities, the throughput mode
 
 
-@pytest.mark.parametrize("T", [4, 6])
+@pytest.mark.parametrize("T,tau", [(4, 0.05), (6, 0.05), (5, 0.3)])
 @pytest.mark.parametrize("chain", [0, 2, 1])
-def test_walk_n4096_matches_fp64_oracle(hip, chain, T):
-    """One walk at [B,T,N,C] = [1,T,4096,128] (bench.py --workload chain quotes T = 32 of the same) in every chain arithmetic:
-    logits, every cycle product At_k, loss and dLoss/dEmb against the oracle's formulas evaluated in float64 on the GPU."""
+def test_walk_n4096_matches_fp64_oracle(hip, chain, T, tau):
+    """One walk at [B,T,N,C] = [1,T,4096,128] (bench.py --workload chain quotes T = 32 of the same, tau 0.05) in every chain
+    arithmetic: logits, every cycle product At_k, loss and dLoss/dEmb against the oracle's formulas evaluated in float64 on the
+    GPU.  tau = 0.05 gives peaked transition rows (a near-permutation walk), tau = 0.3 flat ones (thousands of comparable terms
+    per dot product)."""
     import model as crw_model
-    tau, C = 0.05, 128
+    C = 128
     g = torch.Generator().manual_seed(11 + T)
     base = torch.randn(1, 1, N4K, C, generator=g)
     emb = (base + 0.5 * torch.randn(1, T, N4K, C, generator=g)).cuda().requires_grad_(True)
@@ -111,7 +115,7 @@ def test_walk_n4096_matches_fp64_oracle(hip, chain, T):
     gscale = demb_ref.abs().max()
     worst = (gerr - grtol * demb_ref.abs() - gafrac * gscale).max().item()
     assert worst <= 0, (chain, "demb", worst, gerr.max().item(), gscale.item())
-    print(f"chain {chain} T {T}: max|dAt| {err.max().item():.3e} (max At {scale.max().item():.3e}), max rel dAt "
+    print(f"chain {chain} T {T} tau {tau}: max|dAt| {err.max().item():.3e} (max At {scale.max().item():.3e}), max rel dAt "
           f"{(err / (At_ref.abs() + afrac * scale)).max().item():.3e}, dloss {abs(loss.item() - loss_ref):.3e}, max|ddemb|/max|demb| "
           f"{(gerr.max() / gscale).item():.3e}")
     # the walk that computes its own statistics (stats kernel) takes the same state layout

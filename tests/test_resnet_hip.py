@@ -45,18 +45,24 @@ def nhwc(out, P, H, W, C):
 CONVS = [  # Hin, Win, Cin, Cout, k, stride, pad
     (5, 5, 64, 64, 3, 1, 1), (5, 5, 64, 128, 3, 2, 1), (3, 3, 128, 128, 3, 1, 1), (5, 5, 64, 128, 1, 2, 0),
     (3, 3, 128, 256, 3, 2, 1), (2, 2, 256, 256, 3, 1, 1), (2, 2, 256, 512, 3, 2, 1), (1, 1, 512, 512, 3, 1, 1),
-    (2, 2, 256, 512, 1, 2, 0), (1, 1, 512, 128, 1, 1, 0), (4, 6, 64, 64, 3, 1, 1)]
+    (2, 2, 256, 512, 1, 2, 0), (1, 1, 512, 128, 1, 1, 0), (4, 6, 64, 64, 3, 1, 1),
+    # 32 x 32 patches (scripts/test/test_mc1.py:19): maps 9 -> 9 -> 5 -> 3 -> 2, then the head over the 2 x 2 map as ONE product whose
+    # kernel covers the map (global average pool + linear, src/encoder.py:264-266); a 1 x 3 final map (16 x 80 patches) likewise
+    (9, 9, 64, 64, 3, 1, 1), (9, 9, 64, 128, 3, 2, 1), (5, 5, 128, 256, 3, 2, 1), (3, 3, 256, 512, 3, 2, 1), (2, 2, 512, 512, 3, 1, 1),
+    (2, 2, 512, 128, (2, 2), 1, 0), (1, 3, 512, 128, (1, 3), 1, 0)]
 
 
 @pytest.mark.parametrize("geo", CONVS)
 @pytest.mark.parametrize("P", [200, 128])
 def test_rn_conv_forward_backward_wgrad_match_torch(hip, geo, P):
     Hin, Win, Cin, Cout, k, s, pad = geo
-    Hout, Wout = (Hin + 2 * pad - k) // s + 1, (Win + 2 * pad - k) // s + 1
-    g = torch.Generator().manual_seed(Hin * 100 + Cin + k + s)
+    kh, kw = k if isinstance(k, tuple) else (k, k)
+    Hout, Wout = (Hin + 2 * pad - kh) // s + 1, (Win + 2 * pad - kw) // s + 1
+    g = torch.Generator().manual_seed(Hin * 100 + Cin + kh + s)
     x = torch.randn(P, Cin, Hin, Win, generator=g).cuda()
-    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
-    bias = torch.randn(Cout, generator=g).cuda() if k == 1 and Hin == 1 else None
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) / (Cin * kh * kw) ** 0.5).cuda()
+    bias = torch.randn(Cout, generator=g).cuda() if Hout * Wout == 1 and Cout == 128 else None
+    k = (kh, kw)
     dy = torch.randn(P, Cout, Hout, Wout, generator=g).cuda()
     xp, xv = planes(hip, x)
     dp, dv = planes(hip, dy)
@@ -68,7 +74,7 @@ def test_rn_conv_forward_backward_wgrad_match_torch(hip, geo, P):
     gx, gw = torch.autograd.grad(ref, (xv, wv), dv)
     scale = ref.abs().max().item()
 
-    out, part = hip.rn_conv(hip.RN_FWD, P, (Hin, Win, Cin), (Hout, Wout), Cout, (k, k), s, pad, xp, wp[:2], bias=bias, stats=True)
+    out, part = hip.rn_conv(hip.RN_FWD, P, (Hin, Win, Cin), (Hout, Wout), Cout, k, s, pad, xp, wp[:2], bias=bias, stats=True)
     got = nhwc(out, P, Hout, Wout, Cout).double()
     torch.testing.assert_close(got, ref.detach(), rtol=1e-4, atol=2e-5 * scale)
     if bias is None:
@@ -78,11 +84,11 @@ def test_rn_conv_forward_backward_wgrad_match_torch(hip, geo, P):
         torch.testing.assert_close(pt[:, 0], ref.detach().sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * scale)
         torch.testing.assert_close(pt[:, 1], (ref.detach() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * scale)
 
-    gin, _ = hip.rn_conv(hip.RN_BWD, P, (Hout, Wout, Cout), (Hin, Win), Cin, (k, k), s, pad, dp, wp[2:])
+    gin, _ = hip.rn_conv(hip.RN_BWD, P, (Hout, Wout, Cout), (Hin, Win), Cin, k, s, pad, dp, wp[2:])
     torch.testing.assert_close(nhwc(gin, P, Hin, Win, Cin).double(), gx, rtol=1e-4, atol=2e-5 * gx.abs().max().item())
     assert not gin[P:].any()
 
-    dw = hip.rn_wgrad(hip.RN_FWD, P, (Hin, Win, Cin), (Hout, Wout, Cout), (k, k), s, pad, xp, dp)
+    dw = hip.rn_wgrad(hip.RN_FWD, P, (Hin, Win, Cin), (Hout, Wout, Cout), k, s, pad, xp, dp)
     torch.testing.assert_close(dw.double(), gw, rtol=1e-4, atol=2e-5 * gw.abs().max().item())
 
 
@@ -332,11 +338,15 @@ def _teacher_forced_forward(ref, x64, dec):
     return body.fc(torch.flatten(body.avgpool(a), 1)), flips
 
 
-@pytest.mark.parametrize("pos_embed,P,path", [(False, 160, "bf16x3"), (True, 70, "bf16x3"), (False, 130, "stepwise")])
-def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path):
+@pytest.mark.parametrize("pos_embed,P,path,hw", [(False, 160, "bf16x3", (16, 16)), (True, 70, "bf16x3", (16, 16)), (False, 130, "stepwise", (16, 16)),
+                                                  (False, 140, "bf16x3", (32, 32)), (True, 40, "stepwise", (32, 32)), (False, 70, "bf16x3", (20, 27)),
+                                                  (False, 30, "bf16x3", (40, 64))])
+def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path, hw):
     """The whole encoder: HIP forward / backward / running statistics against the same module run on PyTorch ops in fp64.
     path "bf16x3" = the whole pass from native code (crw_rn_train_fwd / _bwd, what training uses), "stepwise" = the same
-    kernels launched one by one from Python (resnet_hip.HipResnetFn).
+    kernels launched one by one from Python (resnet_hip.HipResnetFn).  Patch sizes: 16x16 (patch-per-wave stem, 1x1 final map),
+    32x32 (the reference's cfg5 encoder input, scripts/test/test_mc1.py:19: gathered stem, 2x2 final map -> the average pool +
+    head as one product over the map), 20x27 (stem rows over two column tiles, 1x1 final map), 40x64 (3x4 final map).
 
     Two references.  FREE-RUNNING fp64 modules: features, running statistics, and direction + norm of every gradient (an fp32-grade
     forward and an fp64 one may pick different arg-max pixels / ReLU gates where two candidates differ by less than ~1e-5, which
@@ -359,7 +369,7 @@ def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path
     probe = copy.deepcopy(enc)
     probe.hip_convs = "stepwise"
     enc.hip_convs = path
-    x = torch.randn(P, 2 if pos_embed else 1, 16, 16).cuda()
+    x = torch.randn(P, 2 if pos_embed else 1, *hw).cuda()
     gy = torch.randn(P, 128).cuda()
     ref.train()
     y_ref = ref(x.double())
@@ -379,7 +389,7 @@ def test_resnet_hip_matches_pytorch_modules(hip, monkeypatch, pos_embed, P, path
     y_tf.backward(gy.double())
     # imposing the device's choices moves the fp64 forward by no more than the flips' own margins
     torch.testing.assert_close(y_tf.detach(), y_ref.detach(), rtol=1e-3, atol=1e-3 * y_ref.abs().max().item())
-    print(f"routing decisions where the device and fp64 differ (P = {P}, {path}): {flips}")
+    print(f"routing decisions where the device and fp64 differ (P = {P}, {hw[0]}x{hw[1]}, {path}): {flips}")
     for (k, p), (_, q), (_, t) in zip(enc.named_parameters(), ref.named_parameters(), forced.named_parameters()):
         assert p.grad is not None, k
         if k == "fc0.bias":  # true gradient is zero (it feeds a BatchNorm); both sides hold rounding noise
@@ -445,8 +455,10 @@ def test_resnet_step_at_bench_batch_matches_fp64(hip, monkeypatch):
             continue
         a, b_, c_ = p.grad.double().flatten(), q.grad.flatten(), t.grad.flatten()
         cos = float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
-        assert cos > 0.9999 and abs(float(a.norm() / b_.norm()) - 1) < 1e-2, (k, cos, float(a.norm()), float(b_.norm()))
-        tol = 2e-2 if k == "fc0.weight" else 5e-3
+        # fc0.weight with ONE input channel survives only through BatchNorm's eps (a difference of sums ~1e5 times larger,
+        # test_rn_stem_matches_torch): 3 % there, 1 % everywhere else
+        assert cos > 0.9999 and abs(float(a.norm() / b_.norm()) - 1) < (3e-2 if k == "fc0.weight" else 1e-2), (k, cos, float(a.norm()), float(b_.norm()))
+        tol = 3e-2 if k == "fc0.weight" else 5e-3
         scale = max(c_.abs().max().item(), 1e-30)
         bad = (a - c_).abs() > tol * scale + tol * c_.abs()
         assert not bad.any(), (k, int(bad.sum()), a.numel(), float(((a - c_).abs() / (scale + c_.abs())).max()))
@@ -480,29 +492,66 @@ def test_resnet_native_and_stepwise_paths_agree(hip):
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=1e-4 * max(1e-6, q.grad.abs().max().item()), msg=lambda m: f"{k}: {m}")
 
 
-def test_resnet_forward_without_grad_is_the_same_forward(hip):
-    """Inference as the reference runs it (scripts/test/test_all.py: the default encoder is the Resnet, never `.eval()`'d, under
-    `torch.no_grad()`): the native forward, batch statistics and running-statistics update included, bit for bit the forward of
-    a training step; through `utils.propagate` it yields a full label map."""
+@pytest.mark.parametrize("hw,ov", [((16, 16), 8), ((32, 32), 24)])
+@pytest.mark.parametrize("train_mode", [True, False])
+def test_resnet_inference_through_propagate(hip, monkeypatch, hw, ov, train_mode):
+    """Inference as the reference runs it with its default encoder, under `torch.no_grad()`: never `.eval()`'d in
+    scripts/test/test_all.py / test_mc1.py (32x32 patches, overlap 24: test_mc1.py:19,21) -- there the forward is bit for bit the
+    forward of a training step, batch statistics and running-statistics update included --, `encoder.train(False)` in
+    scripts/test/test.py:42 -- BatchNorm on the running statistics, nothing updated.  Both on the hand-written kernels (every
+    PyTorch convolution / batch-norm entry point disabled), through `utils.propagate`; the label map against the oracle's label
+    propagation on the device's features (teacher-forced fp64 audit: every disagreement must be a floating-point near-tie)."""
     import copy
     import encoder as crw_encoder
     import utils as crw_utils
     from imported.labelprop import LabelPropVOS_CRW
+    from oracle import crw_oracle as orc
     torch.manual_seed(5)
+    T, N, M = 6, 20, 4
+    h, w = hw
     a = crw_encoder.Resnet(False).cuda()
+    g = torch.Generator().manual_seed(hw[0])
+    rows = N * (h - ov) + ov
+    rg = torch.sin(torch.arange(rows)[:, None] / 9.0 + 0.01 * torch.arange(T * w)[None, :]) + 0.5 * torch.randn(rows, T * w, generator=g)
+    seq = torch.stack([torch.stack([rg[n * (h - ov):n * (h - ov) + h, t * w:(t + 1) * w] for n in range(N)]) for t in range(T)]).cuda()
+    x = seq.reshape(T * N, 1, h, w)
+    a(x).sum().backward()  # one training step's worth of running statistics
+    a.train(train_mode)
     b = copy.deepcopy(a)
-    x = torch.randn(6 * 20, 1, 16, 16).cuda()
-    ya = a(x)
-    with torch.no_grad():
-        yb = b(x)
-    assert not yb.requires_grad and torch.equal(ya.detach(), yb)
-    for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
-        assert torch.equal(p, q), k
-    seq = x.reshape(6, 20, 16, 16)
-    seg = (torch.arange(20 * 8 + 8)[:, None] * 4 // (20 * 8 + 8)).float().repeat(1, 16).cuda()
-    pred, xent, _ = crw_utils.propagate(seq, seg, b, LabelPropVOS_CRW(dict(CXT_SIZE=4, RADIUS=5, TEMP=0.1, KNN=5)), 4, False, False)
-    assert pred.shape == (20, 6) and xent.shape == (20, 5) and torch.isfinite(pred).all()
-    assert torch.equal(pred[:, 0], crw_utils.seed_labels(seg, 20))
+    cfg = dict(CXT_SIZE=4, RADIUS=5, TEMP=0.1, KNN=5)
+    seg = (torch.arange(rows)[:, None] * M // rows).float().repeat(1, w).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _no_library_convs(monkeypatch)
+        if train_mode:
+            ya = a(x)
+        with torch.no_grad():
+            yb = b(x)
+        stats = [v.clone() for v in b.buffers()]
+        pred, xent, _ = crw_utils.propagate(seq, seg, b, LabelPropVOS_CRW(cfg), M, False, False)
+    monkeypatch.undo()
+    assert not yb.requires_grad
+    if train_mode:
+        assert torch.equal(ya.detach(), yb)
+        for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
+            assert not torch.equal(p, q) or not p.is_floating_point(), k  # propagate() ran the forward once more: statistics moved on
+    else:
+        ref = copy.deepcopy(a).double()
+        ref.hip_convs = None
+        with torch.no_grad():
+            y64 = ref(x.double())
+        torch.testing.assert_close(yb.double(), y64, rtol=1e-3, atol=1e-4 * y64.abs().max().item())
+        for u, v in zip(stats, b.buffers()):
+            assert torch.equal(u, v)  # eval mode updates nothing
+    assert pred.shape == (N, T) and xent.shape == (N, T - 1)
+    assert torch.equal(pred[:, 0], crw_utils.seed_labels(seg, N))
+    feats = hip.normalize(yb.reshape(T, N, -1).float().contiguous())
+    if train_mode:  # propagate's own forward saw the same batch: the same features
+        pred2, L = LabelPropVOS_CRW(cfg).propagate_all(feats, crw_utils.seed_labels(seg, N), M)
+        assert torch.equal(pred, pred2)
+        audit = orc.labelprop_tie_audit(feats.cpu().numpy(), L.cpu().numpy(), pred.cpu().numpy(), cfg["CXT_SIZE"], cfg["RADIUS"],
+                                        cfg["TEMP"], cfg["KNN"], eps=1e-5)
+        assert audit["not_ties"] == 0 and audit["max_soft_err"] <= 1e-4, audit
 
 
 def test_resnet_single_patch_batch_raises_like_batchnorm(hip):
@@ -544,12 +593,16 @@ def test_resnet_native_pass_is_reproducible(hip):
                 assert torch.equal(a, b), f"tensor {k} differs between two runs of the same step"
 
 
-def test_resnet_hip_training_step_matches_reference(hip, monkeypatch):
+@pytest.mark.parametrize("name", ["resnet_train_B2T4N5", "resnet_train_32x32_B2T3N4", "resnet_train_20x27_B1T3N5"])
+def test_resnet_hip_training_step_matches_reference(hip, monkeypatch, name):
     """SURVEY section 8 row a8 on the hand-written kernels: CRW.forward + backward with the reference's DEFAULT encoder against
-    the reference's own CPU run (fixture resnet_train_*), with every PyTorch convolution / batch-norm entry point disabled."""
+    the reference's own CPU run (fixtures resnet_train_*: 16x16 patches; 32x32 with overlap 24, scripts/test/test_mc1.py:19,21;
+    20x27), with every PyTorch convolution / batch-norm entry point disabled.  Where the fixture holds them: the encoder switched
+    to eval mode AFTER the step (scripts/test/test.py:42) -- BatchNorm on the running statistics this step has just updated --
+    against the reference's eval-mode features, and every running statistic."""
     import model as crw_model
     import encoder as crw_encoder
-    g = load_golden("resnet_train_B2T4N5")
+    g = load_golden(name)
     torch.manual_seed(int(g["seed"]))
     enc = crw_encoder.Resnet(False)
     net = crw_model.CRW(enc, float(g["tau"]), False).cuda()
@@ -573,3 +626,17 @@ def test_resnet_hip_training_step_matches_reference(hip, monkeypatch):
         if "grad." + k in g:
             ref = g["grad." + k]
             np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max())
+    if "emb_eval" in g:
+        for k, b in enc.named_buffers():
+            if b.is_floating_point():
+                np.testing.assert_allclose(b.cpu().numpy(), g["buffer." + k], rtol=1e-3, atol=1e-5, err_msg=k)
+        seq = torch.as_tensor(g["seq"]).cuda()
+        enc.train(False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            _no_library_convs(monkeypatch)
+            with torch.no_grad():
+                emb_eval = enc(seq.reshape(-1, 1, *seq.shape[-2:]))
+        monkeypatch.undo()
+        scale = np.abs(g["emb_eval"]).max()
+        np.testing.assert_allclose(emb_eval.cpu().numpy(), g["emb_eval"], rtol=1e-3, atol=1e-4 * scale)
