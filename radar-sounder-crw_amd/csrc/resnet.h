@@ -56,8 +56,13 @@ int rn_make_wgrad(RnWgradArgs &a, int mode, int P, int Hin, int Win, int Cin, in
                   int pad);
 
 // resnet_bn.hip ------------------------------------------------------------------------------------------------------------
+// The sums-with-tail kernels (rn_sums_tail_kernel) count their blocks on RN_TICKET_BLOCKS counters of the CALLER's: `tickets` = one
+// zeroed set (RN_TICKET_BYTES) per stream that may run such a kernel at the same time; the kernels leave them zeroed.
+constexpr int RN_TICKET_BLOCKS = 32, RN_TICKET_BYTES = RN_TICKET_BLOCKS * 4;
+int rn_zero_tickets(unsigned *tickets, int sets, hipStream_t s);
 int launch_rn_bn_stats(const float *part, int R, int C, double count, const float *gamma, const float *beta, float *run_mean,
-                       float *run_var, float momentum, float eps, float *coef, double *ws /* 64 * 2C doubles */, hipStream_t s);
+                       float *run_var, float momentum, float eps, float *coef, double *ws /* 64 * 2C doubles */, unsigned *tickets,
+                       hipStream_t s);
 int launch_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
                        const uint16_t *res_lo, int P, int Ppad, int npix, int C, int relu, uint16_t *y_hi, uint16_t *y_lo, hipStream_t s);
 int launch_rn_bn_pool(const float *Z, const float *coef, int P, int Ppad, int H, int W, int C, uint16_t *y_hi, uint16_t *y_lo,
@@ -66,10 +71,10 @@ size_t rn_bn_bwd_ws_bytes(int P, int npix, int C);
 int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
                      const float *coef_d, int P, int Ppad, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi,
                      uint16_t *dzd_lo, float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws,
-                     hipStream_t s, const float *ext_part = nullptr, int ext_rows = 0);
+                     unsigned *tickets, hipStream_t s, const float *ext_part = nullptr, int ext_rows = 0);
 size_t rn_pool_bwd_ws_bytes(int P, int H, int W, int C);
 int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int Ppad, int H,
-                       int W, int C, uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s);
+                       int W, int C, uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, unsigned *tickets, hipStream_t s);
 size_t rn_stem_ws_bytes();
 int launch_rn_stem_fwd(const float *x, int P, int Ppad, int cin, int h, int w, int Hm, int Wm, const float *w0, const float *b0,
                        const float *gamma, const float *beta, float *run_mean, float *run_var, float momentum, float eps,

@@ -160,7 +160,9 @@ int crw_rn_wgrad(int mode, int P, int Hin, int Win, int Cin, int Hout, int Wout,
   return launch_rn_wgrad(a, dw, (hipStream_t)stream);
 }
 
-size_t crw_rn_bn_stats_ws_bytes(int C) { return C < 1 ? 0 : (size_t)64 * 2 * C * 8; }
+// the sums' doubles, then one set of block tickets (zeroed by the entry point before every launch: the library keeps no state)
+static size_t stats_doubles(int C) { return (size_t)64 * 2 * C; }
+size_t crw_rn_bn_stats_ws_bytes(int C) { return C < 1 ? 0 : stats_doubles(C) * 8 + RN_TICKET_BYTES; }
 
 int crw_rn_bn_stats(const float *part, int P, int G, int C, const float *gamma, const float *beta, float *run_mean, float *run_var,
                     float momentum, float eps, float *coef, void *ws, size_t ws_bytes, crw_stream_t stream) {
@@ -168,8 +170,10 @@ int crw_rn_bn_stats(const float *part, int P, int G, int C, const float *gamma, 
   if (!part || !gamma || !beta || !coef || !ws || P < 1 || G < 1 || C < 1 || (run_mean == nullptr) != (run_var == nullptr))
     return CRW_EINVAL;
   if (ws_bytes < crw_rn_bn_stats_ws_bytes(C)) return CRW_EWORKSPACE;
+  unsigned *tk = (unsigned *)((double *)ws + stats_doubles(C));
+  CRW_TRY(rn_zero_tickets(tk, 1, (hipStream_t)stream));
   return launch_rn_bn_stats(part, (padded(P) / 128) * 2 * G, C, (double)P * G, gamma, beta, run_mean, run_var, momentum, eps, coef,
-                            (double *)ws, (hipStream_t)stream);
+                            (double *)ws, tk, (hipStream_t)stream);
 }
 
 int crw_rn_bn_stats_rows(const float *part, int rows, double count, int C, const float *gamma, const float *beta, float *run_mean,
@@ -178,7 +182,9 @@ int crw_rn_bn_stats_rows(const float *part, int rows, double count, int C, const
   if (!part || !gamma || !beta || !coef || !ws || rows < 1 || count < 1.0 || C < 1 || (run_mean == nullptr) != (run_var == nullptr))
     return CRW_EINVAL;
   if (ws_bytes < crw_rn_bn_stats_ws_bytes(C)) return CRW_EWORKSPACE;
-  return launch_rn_bn_stats(part, rows, C, count, gamma, beta, run_mean, run_var, momentum, eps, coef, (double *)ws, (hipStream_t)stream);
+  unsigned *tk = (unsigned *)((double *)ws + stats_doubles(C));
+  CRW_TRY(rn_zero_tickets(tk, 1, (hipStream_t)stream));
+  return launch_rn_bn_stats(part, rows, C, count, gamma, beta, run_mean, run_var, momentum, eps, coef, (double *)ws, tk, (hipStream_t)stream);
 }
 
 int crw_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
@@ -197,7 +203,9 @@ int crw_rn_bn_pool(const float *Z, const float *coef, int P, int H, int W, int C
   return launch_rn_bn_pool(Z, coef, P, padded(P), H, W, C, y_hi, y_lo, amax, (hipStream_t)stream);
 }
 
-size_t crw_rn_bn_bwd_ws_bytes(int P, int npix, int C) { return (P < 1 || npix < 1 || C < 8) ? 0 : rn_bn_bwd_ws_bytes(P, npix, C); }
+size_t crw_rn_bn_bwd_ws_bytes(int P, int npix, int C) {
+  return (P < 1 || npix < 1 || C < 8) ? 0 : rn_bn_bwd_ws_bytes(P, npix, C) + RN_TICKET_BYTES;
+}
 
 int crw_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
                   const float *coef_d, int P, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi, uint16_t *dzd_lo,
@@ -208,13 +216,15 @@ int crw_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, con
       C > 2048 || (C & (C - 1)))
     return CRW_EINVAL;
   if ((Zd != nullptr) && (!coef_d || !dzd_hi || !dzd_lo || !dgamma_d || !dbeta_d)) return CRW_EINVAL;
-  if (ws_bytes < rn_bn_bwd_ws_bytes(P, npix, C)) return CRW_EWORKSPACE;
+  if (ws_bytes < crw_rn_bn_bwd_ws_bytes(P, npix, C)) return CRW_EWORKSPACE;
+  unsigned *tk = (unsigned *)((char *)ws + rn_bn_bwd_ws_bytes(P, npix, C));
+  CRW_TRY(rn_zero_tickets(tk, 1, (hipStream_t)stream));
   return launch_rn_bn_bwd(g1, g2, mask_hi, Z, coef, Zd, coef_d, P, padded(P), npix, C, dz_hi, dz_lo, Zd ? dzd_hi : nullptr,
-                          Zd ? dzd_lo : nullptr, g_out, dgamma, dbeta, dgamma_d, dbeta_d, ws, (hipStream_t)stream);
+                          Zd ? dzd_lo : nullptr, g_out, dgamma, dbeta, dgamma_d, dbeta_d, ws, tk, (hipStream_t)stream);
 }
 
 size_t crw_rn_pool_bwd_ws_bytes(int P, int H, int W, int C) {
-  return (P < 1 || H < 1 || W < 1 || C < 64) ? 0 : rn_pool_bwd_ws_bytes(P, H, W, C);
+  return (P < 1 || H < 1 || W < 1 || C < 64) ? 0 : rn_pool_bwd_ws_bytes(P, H, W, C) + RN_TICKET_BYTES;
 }
 
 int crw_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int H, int W, int C,
@@ -223,8 +233,10 @@ int crw_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const
   if (!d1 || !amax || !Z || !coef || !dz_hi || !dz_lo || !dgamma || !dbeta || !ws || P < 1 || H < 1 || W < 1 || C < 64 || C % 64 ||
       (C & (C - 1)) || C > 2048)
     return CRW_EINVAL;
-  if (ws_bytes < rn_pool_bwd_ws_bytes(P, H, W, C)) return CRW_EWORKSPACE;
-  return launch_rn_pool_bwd(d1, d2, amax, Z, coef, P, padded(P), H, W, C, dz_hi, dz_lo, dgamma, dbeta, ws, (hipStream_t)stream);
+  if (ws_bytes < crw_rn_pool_bwd_ws_bytes(P, H, W, C)) return CRW_EWORKSPACE;
+  unsigned *tk = (unsigned *)((char *)ws + rn_pool_bwd_ws_bytes(P, H, W, C));
+  CRW_TRY(rn_zero_tickets(tk, 1, (hipStream_t)stream));
+  return launch_rn_pool_bwd(d1, d2, amax, Z, coef, P, padded(P), H, W, C, dz_hi, dz_lo, dgamma, dbeta, ws, tk, (hipStream_t)stream);
 }
 
 size_t crw_rn_stem_ws_bytes(void) { return rn_stem_ws_bytes(); }

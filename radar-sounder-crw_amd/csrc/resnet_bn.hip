@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const double *__res
 // [R][C][NS] when INTERLEAVED) into part2 [R2][NS][C] (doubles), takes a ticket for its channel block, and the block that draws the
 // last ticket merges the R2 rows -- in row order, whichever block it is: the result does not depend on the schedule -- and runs
 // the tail (BatchNorm coefficients / parameter gradients).  Saves the 6-8 us finalize launch behind every reduction of a step.
-constexpr int RN_TICKET_SLOTS = 64, RN_TICKET_BLOCKS = 32;  // consecutive launches use different slots (two streams run these)
-__device__ unsigned g_rn_tickets[RN_TICKET_SLOTS * RN_TICKET_BLOCKS];
+// The tickets (one counter per 64-channel block, RN_TICKET_BLOCKS of them = 128 bytes) belong to the CALLER: a zeroed corner of the
+// workspace it passes, one per stream that runs these kernels at the same time; the kernel leaves them zeroed.  No library state.
 
 struct StatsTail {  // forward: sums (s, ss) -> coef (scale, shift, mean, invstd) + running statistics (see rn_bn_finalize_kernel)
   double count;
@@ -174,9 +174,17 @@ struct BwdTail {  // backward: sums (g, g xhat [, g xhat_d]) -> dbeta, dgamma [,
   }
 };
 
+// Hand-off between the blocks of a channel block, in the terms of the HIP memory model: every thread's partial-sum stores
+// happen-before the block barrier, the barrier happens-before thread 0's ticket fetch_add, which is a RELEASE at agent scope; the
+// block that draws the last ticket did so with an ACQUIRE (acq_rel on the same atomic), so its fetch_add synchronizes-with every
+// earlier one, and its barrier orders the other threads' loads behind it.  On gfx950 the release is one L2 write-back request + wait
+// per BLOCK (the partial sums are written through by their sc1 stores, so it finds nothing of ours to write), the acquire one
+// L1 / L2 invalidate in the one block that goes on.  `relaxed` (CRW_RN_TICKET_RELAXED=1, A/B only) is the round-3 form: relaxed
+// atomics behind s_waitcnt vmcnt(0) -- correct on this chip because the sc1 stores are acknowledged by the memory side before the
+// ticket is drawn and the sc1 loads bypass the non-coherent caches, but outside the language's model.
 template <int NS, bool INTERLEAVED, class Tail>
 __global__ __launch_bounds__(1024) void rn_sums_tail_kernel(const float *__restrict__ in, int R, int C, int RB, double *part2,
-                                                            unsigned *tickets, Tail tail) {
+                                                            unsigned *tickets, int relaxed, Tail tail) {
   __shared__ double sh[NS][16][64];
   __shared__ unsigned ticket;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -202,9 +210,11 @@ __global__ __launch_bounds__(1024) void rn_sums_tail_kernel(const float *__restr
     // XCD's L2 back once per wave: measured +0.8 ms per step.)
     __hip_atomic_store(&part2[((long)blockIdx.y * NS + rl) * C + c], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been acknowledged ...
-  __syncthreads();                                   // ... for every wave of the block, before its ticket is drawn
-  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (relaxed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been acknowledged ...
+  __syncthreads();                                                // ... for every wave of the block, before its ticket is drawn
+  if (threadIdx.x == 0)
+    ticket = relaxed ? __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (ticket != gridDim.y - 1) return;
   const int R2 = gridDim.y;
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(1024) void rn_sums_tail_kernel(const float *__restr
     }
     tail(c, C, tot);
   }
-  if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the slot's next use
+  if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zeroed again for the next launch
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm apply
@@ -869,26 +879,17 @@ inline unsigned grid_for(long n, int per_block = 256, long cap = 8192) {
 
 }  // namespace
 
-unsigned *rn_ticket_slot() {
-  static unsigned *base = nullptr;
-  static std::atomic<unsigned> next{0};
-  if (!base && hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_rn_tickets)) != hipSuccess) {
-    g_last_hip_error = (int)hipGetLastError();
-    return nullptr;
-  }
-  return base + (size_t)(next.fetch_add(1) % RN_TICKET_SLOTS) * RN_TICKET_BLOCKS;
-}
-
-// in [R][NS][C] (or [R][C][NS]) fp32 -> sums over R per channel, handed to `tail` by the last block; part2: 64 * NS * C doubles
+// in [R][NS][C] (or [R][C][NS]) fp32 -> sums over R per channel, handed to `tail` by the last block; part2: 64 * NS * C doubles;
+// tickets: RN_TICKET_BLOCKS zeroed counters of the caller's (left zeroed)
 template <int NS, bool INTERLEAVED, class Tail>
-int rn_sums_tail(const float *in, int R, int C, double *part2, const Tail &tail, hipStream_t s) {
-  if ((C + 63) / 64 > RN_TICKET_BLOCKS) return CRW_EINVAL;
-  unsigned *tk = rn_ticket_slot();
-  if (!tk) return CRW_EHIP;
+int rn_sums_tail(const float *in, int R, int C, double *part2, unsigned *tickets, const Tail &tail, hipStream_t s) {
+  if ((C + 63) / 64 > RN_TICKET_BLOCKS || !tickets) return CRW_EINVAL;
+  static const int relaxed = (getenv("CRW_RN_TICKET_RELAXED") && getenv("CRW_RN_TICKET_RELAXED")[0] == '1') ? 1 : 0;
   const int want = NS * C >= 256 ? 32 : 64;
   const int RB = (R + want - 1) / want > 0 ? (R + want - 1) / want : 1;
   const int R2 = (R + RB - 1) / RB;
-  hipLaunchKernelGGL((rn_sums_tail_kernel<NS, INTERLEAVED, Tail>), dim3((C + 63) / 64, R2), dim3(1024), 0, s, in, R, C, RB, part2, tk, tail);
+  hipLaunchKernelGGL((rn_sums_tail_kernel<NS, INTERLEAVED, Tail>), dim3((C + 63) / 64, R2), dim3(1024), 0, s, in, R, C, RB, part2, tickets,
+                     relaxed, tail);
   return check_launch();
 }
 
@@ -902,10 +903,18 @@ int rn_rows_reduce(const float *in, int R, int W, double *ws, hipStream_t s) {
   return R2;
 }
 
+int rn_zero_tickets(unsigned *tickets, int sets, hipStream_t s) {
+  if (hipMemsetAsync(tickets, 0, (size_t)sets * RN_TICKET_BYTES, s) != hipSuccess) {
+    g_last_hip_error = (int)hipGetLastError();
+    return CRW_EHIP;
+  }
+  return CRW_OK;
+}
+
 int launch_rn_bn_stats(const float *part, int R, int C, double count, const float *gamma, const float *beta, float *run_mean,
-                       float *run_var, float momentum, float eps, float *coef, double *ws, hipStream_t s) {
+                       float *run_var, float momentum, float eps, float *coef, double *ws, unsigned *tickets, hipStream_t s) {
   const StatsTail tail{count, gamma, beta, run_mean, run_var, momentum, eps, coef};
-  return rn_sums_tail<2, true>(part, R, C, ws, tail, s);
+  return rn_sums_tail<2, true>(part, R, C, ws, tickets, tail, s);
 }
 
 int launch_rn_bn_apply(const float *Z, const float *coef, const float *Zd, const float *coef_d, const uint16_t *res_hi,
@@ -933,7 +942,7 @@ size_t rn_bn_bwd_ws_bytes(int P, int npix, int C) {
 int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, const float *Z, const float *coef, const float *Zd,
                      const float *coef_d, int P, int Ppad, int npix, int C, uint16_t *dz_hi, uint16_t *dz_lo, uint16_t *dzd_hi,
                      uint16_t *dzd_lo, float *g_out, float *dgamma, float *dbeta, float *dgamma_d, float *dbeta_d, void *ws,
-                     hipStream_t s, const float *ext_part, int ext_rows) {
+                     unsigned *tickets, hipStream_t s, const float *ext_part, int ext_rows) {
   if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CRW_EINVAL;
   const long rows = (long)P * npix;
   int rpb = (int)((rows + 2047) / 2048);  // ~2048 blocks, at least 256 rows each (the workspace holds rows / 256 + 1 partials)
@@ -958,7 +967,7 @@ int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, 
   {
     const BwdTail<3> t3{(double)rows, dgamma, dbeta, dgamma_d, dbeta_d, kc};
     const BwdTail<2> t2{(double)rows, dgamma, dbeta, dgamma_d, dbeta_d, kc};
-    const int st = NS == 3 ? rn_sums_tail<3, false>(sums, srows, C, part2, t3, s) : rn_sums_tail<2, false>(sums, srows, C, part2, t2, s);
+    const int st = NS == 3 ? rn_sums_tail<3, false>(sums, srows, C, part2, tickets, t3, s) : rn_sums_tail<2, false>(sums, srows, C, part2, tickets, t2, s);
     if (st != CRW_OK) return st;
   }
   const long real = rows * C / 8, total = (long)Ppad * npix * C / 8;
@@ -970,7 +979,7 @@ int launch_rn_bn_bwd(const float *g1, const float *g2, const uint16_t *mask_hi, 
 size_t rn_pool_bwd_ws_bytes(int P, int H, int W, int C) { return rn_bn_bwd_ws_bytes(P, H * W, C); }
 
 int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, const float *Z, const float *coef, int P, int Ppad, int H,
-                       int W, int C, uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, hipStream_t s) {
+                       int W, int C, uint16_t *dz_hi, uint16_t *dz_lo, float *dgamma, float *dbeta, void *ws, unsigned *tickets, hipStream_t s) {
   if (C % 8 || C / 8 > 256 || 256 % (C / 8)) return CRW_EINVAL;
   const long rows = (long)P * H * W;
   int rpb = (int)((rows + 2047) / 2048);
@@ -983,7 +992,7 @@ int launch_rn_pool_bwd(const float *d1, const float *d2, const uint8_t *amax, co
                      part);
   {
     const BwdTail<2> t2{(double)rows, dgamma, dbeta, nullptr, nullptr, kc};
-    const int st = rn_sums_tail<2, false>(part, nblk, C, part2, t2, s);
+    const int st = rn_sums_tail<2, false>(part, nblk, C, part2, tickets, t2, s);
     if (st != CRW_OK) return st;
   }
   const long real = rows * C / 8, total = (long)Ppad * H * W * C / 8;

@@ -65,6 +65,7 @@ struct Plan {
   // scratch
   float *part, *part_d, *redpart;   // part_d / stats_ws_d: the shortcut branch computes beside the main one (side stream)
   double *stats_ws, *stats_ws_d;
+  unsigned *tickets;  // two sets of block counters (caller's stream, side stream) for the sums-with-tail kernels; zeroed per pass
   void *stem_ws;
   Planes dO, dzb[4], dza[4], dzd[4], dz1;  // per block: the weight gradients read them on a side stream while the chain moves on
   float *g[2], *gA, *dX0;
@@ -135,6 +136,7 @@ struct Plan {
     redpart = take<float>(part_max * 2);  // [rows][3][C] against [rows][C][2]
     stats_ws = take<double>((size_t)64 * 2 * 512);
     stats_ws_d = take<double>((size_t)64 * 2 * 512);
+    tickets = take<unsigned>(2 * RN_TICKET_BLOCKS);
     stem_ws = take<char>(rn_stem_ws_bytes());
     dO = planes(pp * FEAT);
     for (int i = 0; i < 4; ++i) {
@@ -288,7 +290,9 @@ int forward_pass(bool training, const float *x, int P, int cin, int h, int w, co
   // one BatchNorm's coef[4][C]: batch statistics from the producing product's per-tile partials, or the running statistics
   auto bn_coef = [&](const float *part, int rows, int C, double cnt, const float *gamma, const float *beta, int bn, float *coef, double *sws,
                      hipStream_t st) {
-    if (training) return launch_rn_bn_stats(part, rows, C, cnt, gamma, beta, rm(bn), rv(bn), momentum, eps, coef, sws, st);
+    if (training)
+      return launch_rn_bn_stats(part, rows, C, cnt, gamma, beta, rm(bn), rv(bn), momentum, eps, coef, sws,
+                                pl.tickets + (sws == pl.stats_ws_d ? RN_TICKET_BLOCKS : 0), st);
     return launch_rn_bn_coef_eval(gamma, beta, rm(bn), rv(bn), eps, C, coef, st);
   };
   // side stream: the weight packing runs beside the stem (which does not need it), each shortcut convolution + its statistics
@@ -300,6 +304,7 @@ int forward_pass(bool training, const float *x, int P, int cin, int h, int w, co
   auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };
   auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };
   SideJoin guard{s, sw};
+  CRW_TRY(rn_zero_tickets(pl.tickets, 2, s));
 
   // all convolution / linear weights -> hi / lo planes (forward and backward-data layouts), one launch
   CRW_TRY(fork());
@@ -424,6 +429,7 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   g_side.used = 0;
   auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };  // side stream sees what the chain has produced
   SideJoin guard{s, sw};  // error paths included: the caller's stream waits for whatever the side stream still holds
+  CRW_TRY(rn_zero_tickets(pl.tickets, 2, s));
 
   // head (one product over layer4's hl x wl map, see Plan): per-pixel weight gradients, then their mean = fc.weight's gradient
   const int khead = pl.npl > 1 ? pl.hl * 256 + pl.wl : 1;
@@ -455,14 +461,14 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
     // block output: bn2 (+ the shortcut's BatchNorm); an identity shortcut hands the masked gradient on in `gin`
     CRW_TRY(launch_rn_bn_bwd(g, nullptr, r.Aout.hi, r.Zb, r.cb, r.Zd, r.cd, P, pl.Ppad, npix, b.cout, pl.dzb[i].hi, pl.dzb[i].lo, b.down ? pl.dzd[i].hi : nullptr,
                              b.down ? pl.dzd[i].lo : nullptr, b.down ? nullptr : gin, gq[4], gq[5], b.down ? gq[7] : nullptr,
-                             b.down ? gq[8] : nullptr, pl.bnbwd_ws, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
+                             b.down ? gq[8] : nullptr, pl.bnbwd_ws, pl.tickets, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
     CRW_TRY(fork());
     CRW_TRY(wgrad(sw, RN_MODE_FWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, r.Aa, pl.dzb[i], gq[3], pl.wgrad_ws));
     if (b.down) CRW_TRY(wgrad(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 1, b.stride, 0, Ain, pl.dzd[i], gq[6], pl.wgrad_ws));
     CRW_TRY(conv(s, RN_MODE_BWD, P, b.hout, b.wout, b.cout, b.hout, b.wout, b.cout, 3, 1, 1, pl.dzb[i], r.wb.bh, r.wb.bl, nullptr, pl.gA, nullptr, false,
                  fuse_red ? Red{r.Aa.hi, r.Za, r.ca, nullptr, nullptr, pl.redpart} : Red()));
     CRW_TRY(launch_rn_bn_bwd(pl.gA, nullptr, r.Aa.hi, r.Za, r.ca, nullptr, nullptr, P, pl.Ppad, npix, b.cout, pl.dza[i].hi, pl.dza[i].lo, nullptr, nullptr,
-                             nullptr, gq[1], gq[2], nullptr, nullptr, pl.bnbwd_ws, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
+                             nullptr, gq[1], gq[2], nullptr, nullptr, pl.bnbwd_ws, pl.tickets, s, fuse_red ? pl.redpart : nullptr, rrows * npix));
     CRW_TRY(fork());
     CRW_TRY(wgrad(sw, RN_MODE_FWD, P, b.hin, b.win, b.cin, b.hout, b.wout, b.cout, 3, b.stride, 1, Ain, pl.dza[i], gq[0], pl.wgrad_ws));
     if (b.down) {
@@ -479,7 +485,7 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   }
   float *g1 = g, *g2 = nullptr;
   // max-pool + bn1, stem convolution, stem
-  CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.amax1, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, s));
+  CRW_TRY(launch_rn_pool_bwd(g1, g2, pl.amax1, pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.dz1.hi, pl.dz1.lo, grads[5], grads[6], pl.poolbwd_ws, pl.tickets, s));
   auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };  // the caller's stream waits for the side stream
   if (pl.stem16) {
     CRW_TRY(fork());

@@ -625,7 +625,10 @@ def test_resnet_hip_training_step_matches_reference(hip, monkeypatch, name):
         assert abs(got - ref_norm) <= 2e-2 * ref_norm + 1e-4, (k, got, ref_norm)
         if "grad." + k in g:
             ref = g["grad." + k]
-            np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max())
+            # fc0.weight with ONE input channel survives only through BatchNorm's eps -- the difference of sums ~1e5 times larger
+            # (test_rn_stem_matches_torch) -- and the reference's number is itself an fp32 evaluation of that difference: 5 %
+            rtol = 5e-2 if k == "fc0.weight" else 2e-2
+            np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=rtol, atol=2e-3 * np.abs(ref).max(), err_msg=k)
     if "emb_eval" in g:
         for k, b in enc.named_buffers():
             if b.is_floating_point():
