@@ -43,12 +43,15 @@ def parse():
                          "bf16 = HIP kernels, plain bf16 operands; torch = PyTorch-ROCm (MIOpen) fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel roofline probes")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=0,
                     help="the timed region of --steps steps is run this many times; value / ms_per_step = the MEDIAN repeat "
-                         "(min / max on the line); every repeat is bracketed by barrier + synchronize like a single one")
+                         "(min / max on the line); every repeat is bracketed by barrier + synchronize like a single one.  0 (default): "
+                         "as many repeats as keep the GPU busy for about --gpu-seconds (at least 5), so that an outside sampler of GPU "
+                         "activity sees the run")
+    ap.add_argument("--gpu-seconds", type=float, default=10.0, help="target duration of all timed repeats together when --repeats is 0")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket the conv kernels of the timed steps with HIP events (A/B of their overhead)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline's all-threads leg (a 1-thread step follows)")
     ap.add_argument("--workload", default="radargram", choices=["radargram", "chain", "labelprop", "shared", "dense", "train32"],
                     help="radargram: the BASELINE metric (default); chain: kernel-only stress shape K of SURVEY "
                          "8(d): affinity + walk fwd+bwd on unit-norm random features, no encoder; labelprop: BASELINE "
@@ -56,6 +59,7 @@ def parse():
                          "shared: all 225 overlapping items of the radargram per step, patch-columns encoded once "
                          "(SURVEY 8 f1); dense: shape family D of SURVEY 8(d) = the radargram workload at --overlap 15 0 "
                          "(N = 497 nodes per column)")
+    ap.add_argument("--train-steps", type=int, default=0, help="labelprop workload: Adam steps on the cycle loss before the timed passes")
     ap.add_argument("--nodes", type=int, default=4096, help="N of the chain workload")
     ap.add_argument("--walk", type=int, default=32, help="T (frames) of the chain workload")
     ap.add_argument("--modes", default="f32,bf16x3,bf16", help="chain arithmetics the chain workload runs (profiling one at a time)")
@@ -134,10 +138,11 @@ def chain_probe_bf16(n, batch, split, iters=10):
 def _rn_pairs(Hin, Win, Hout, Wout, k, stride, pad):
     """number of (output pixel, tap) pairs of a k x k convolution whose tap falls inside the Hin x Win input map"""
     n = 0
+    kh, kw = (k >> 8, k & 255) if k >= 256 else (k, k)  # (the head over an hl x wl map records its kernel as hl * 256 + wl)
     for oy in range(Hout):
         for ox in range(Wout):
-            for ky in range(k):
-                for kx in range(k):
+            for ky in range(kh):
+                for kx in range(kw):
                     iy, ix = oy * stride + ky - pad, ox * stride + kx - pad
                     n += 0 <= iy < Hin and 0 <= ix < Win
     return n
@@ -221,6 +226,33 @@ def resnet_event_kernels(ev, P, steps):
     return out
 
 
+def host_cpu():
+    """CPU model, physical cores and hardware threads of this box (from /proc/cpuinfo), and the share this process may run on"""
+    model, cores, threads = "unknown", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                threads += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:  # blank line = end of one processor's record
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": len(cores) or None, "hw_threads": threads or (os.cpu_count() or 1), "threads_available_to_this_job": avail}
+
+
 def cpu_baseline(budget_s):
     """The oracle (pure torch-CPU restatement, validated against the reference) timed on this
     box's host cores on a bounded sample of the same workload: ONE item [1,32,63,16,16] per step."""
@@ -242,7 +274,8 @@ def cpu_baseline(budget_s):
 
     # the box exposes more hardware threads than this job's CPU share: time the step at a few
     # thread counts and report the fastest (cores = threads actually used for that figure)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpu = host_cpu()
+    avail = cpu["threads_available_to_this_job"]
     candidates = sorted({min(avail, c) for c in (16, 32)})  # all hw threads oversubscribe this job's CPU share
     best = None
     for threads in candidates:
@@ -259,7 +292,15 @@ def cpu_baseline(budget_s):
             best = (med, threads, len(times))
     med, threads, n = best
     cols = T_SEQ * PATCH[1]
+    torch.set_num_threads(1)  # the 1-thread figure beside the all-cores one (one step: it takes several seconds)
+    t0 = time.time()
+    step()
+    one = time.time() - t0
+    torch.set_num_threads(threads)
     return {"value": cols / med, "unit": "radargram columns/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"], "hw_threads": cpu["hw_threads"],
+            "threads_available_to_this_job": avail,
+            "one_thread": {"value": cols / one, "unit": "radargram columns/s", "cores": 1, "sample": f"the same step once at 1 thread ({one:.2f} s)"},
             "sample": f"1 item [1,{T_SEQ},63,16,16] fwd+bwd per step, median of {n} steps ({med:.3f} s/step) at "
                       f"{threads} threads (fastest of {candidates}; {avail} hw threads visible), "
                       f"torch {torch.__version__} CPU ops"}
@@ -378,9 +419,32 @@ def bench_labelprop(args):
     N = seq.shape[1]
     rows = N * 8 + 24
     seg = (torch.arange(rows)[:, None] * M // rows).float().repeat(1, 32).cuda()
+    import crw_hip
     torch.manual_seed(11)
-    enc = crw_encoder.CNN(False).cuda().eval()
+    if args.model == 1:
+        # the reference's own cfg5 encoder: create_model(id = 1) = Resnet on 32 x 32 patches, never .eval()'d (scripts/test/
+        # test_mc1.py:19-21,40-46): train-mode BatchNorm on the statistics of the radargram's 12 288 patches, hand-written kernels
+        enc = crw_encoder.Resnet(False).cuda().train(True)
+    else:
+        enc = crw_encoder.CNN(False).cuda().eval()
     cfg = dict(CXT_SIZE=80, RADIUS=10, TEMP=0.1, KNN=20)
+    if args.train_steps:  # Adam steps on the cycle loss first: a trained encoder separates the nodes' features (no near-ties left)
+        import model as crw_model
+        import dist as crw_dist
+        import optim as crw_optim
+        net = crw_model.CRW(enc, 0.01, False).cuda().train(True)
+        bucket = crw_dist.FlatGradBucket(net.parameters(), lazy=True)
+        opt = crw_optim.FlatAdam(bucket, lr=1e-3)
+        items = crw_dataset.RGDataset.synthetic(H, 2048, 16, (32, 32), (24, 0), seed=12)
+        batch = torch.stack([items[i] for i in range(0, len(items), max(1, len(items) // 4))][:4]).cuda()
+        for _ in range(args.train_steps):
+            bucket.zero()
+            tl, _ = net(batch)
+            tl.backward()
+            bucket.all_reduce_mean()
+            opt.step()
+        if args.model == 0:
+            enc.eval()
 
     def run():
         return crw_utils.propagate(seq, seg, enc, LabelPropVOS_CRW(cfg), M, False, False)
@@ -388,15 +452,24 @@ def bench_labelprop(args):
     for _ in range(max(1, args.warmup)):
         pred, xent, _ = run()
     torch.cuda.synchronize()
-    import crw_hip
     if not args.no_events:
         crw_hip.KERNEL_EVENTS = {}  # HIP events around every map-convolution call of the timed passes, on the launch stream
+        if args.model == 1:
+            crw_hip.rn_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pred, xent, _ = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     kernels = []
+    if args.model == 1 and not args.no_events:
+        ev = {}
+        for rec in crw_hip.rn_timing_read():
+            key = ("rn_conv" if rec.kind == 0 else "rn_wgrad", rec.mode, *list(rec.g), rec.k, rec.stride, rec.pad)
+            ev.setdefault(key, []).append(rec.ms)
+        crw_hip.rn_timing(False)
+        crw_hip.KERNEL_EVENTS = None
+        kernels = resnet_event_kernels(ev, T * N, args.steps)
     if crw_hip.KERNEL_EVENTS:
         ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
         P, mh, mw = T * N, 26, 26  # 32 x 32 patches -> 26 x 26 maps after the front end
@@ -418,7 +491,7 @@ def bench_labelprop(args):
         kernels.sort(key=lambda k: -k["launch_us"])
     # label propagation alone (features resident), the part the HIP kernels own
     with torch.no_grad():
-        feats = crw_hip_normalize(enc, seq, T, N)
+        feats = crw_hip_normalize(enc, seq, T, N)  # (the Resnet in train mode: the same batch -> the same batch statistics and features)
     lp = LabelPropVOS_CRW(cfg)
     seed = crw_utils.seed_labels(seg, N)
     for _ in range(2):
@@ -445,7 +518,15 @@ def bench_labelprop(args):
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                       "data": "synthetic", "dtype": "f32",
                       "config": {"workload": f"{H}x{W} radargram, 32x32 patches overlap (24,0) -> [T,N]=[{T},{N}], {cfg}, "
-                                             "CNN encoder (whole conv trunk on the tiled HIP kernels, FC head on PyTorch-ROCm) + normalise + xent + top-k + gather"},
+                                             + ("Resnet encoder (the reference's create_model(id = 1), train-mode BatchNorm as in scripts/test/test_mc1.py; whole "
+                                                "forward on the hand-written kernels, crw_rn_train_fwd)" if args.model == 1 else
+                                                "CNN encoder (whole conv trunk on the tiled HIP kernels, FC head on PyTorch-ROCm)")
+                                             + " + normalise + xent + top-k + gather",
+                                 "encoder_weights": (f"trained: {args.train_steps} Adam steps on the cycle loss from the seeded initialisation (label map must "
+                                                     "equal the oracle's outright)" if args.train_steps else
+                                                     "random initialisation (seed 11): near-uniform affinities, so the free-running label map may differ "
+                                                     "from the oracle's downstream of floating-point near-ties -- `label_mismatches_not_ties` (teacher-forced "
+                                                     "fp64 audit) must be 0; --train-steps 300 gives the exact-match case")},
                       "labelprop_only": {"ms": dlp * 1e3, "columns_per_s": W / dlp,
                                          "what": "crw_labelprop_topk + crw_labelprop_gather, features resident"},
                       "cpu_baseline": {"value": W / dcpu, "unit": "radargram columns/s", "kind": "port", "cores": torch.get_num_threads(),
@@ -531,6 +612,17 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
+    if args.repeats <= 0:
+        # size the run: one more untimed pass of `steps` steps tells how long a repeat takes; every rank must run the same number
+        # of repeats, so the slowest rank's estimate decides
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        est = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(est, op=torch.distributed.ReduceOp.MAX)
+        args.repeats = int(min(500, max(5, round(args.gpu_seconds / max(est.item(), 1e-4)))))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -539,7 +631,14 @@ def main():
         if args.model == 1 and getattr(enc, "hip_convs", None):
             crw_hip.rn_timing(True)  # the Resnet pass is driven from native code: it records its own events (crw_rn_timing_*)
     rep_elapsed = []
-    for _ in range(max(1, args.repeats)):  # each repeat: EXACTLY --steps steps between barrier + synchronize, MAX over ranks
+    ev_repeats = min(max(1, args.repeats), 5)  # the per-kernel HIP events cover the first 5 repeats (tens of thousands of events otherwise)
+    ev_stash, rn_records = None, None
+    for rep in range(max(1, args.repeats)):  # each repeat: EXACTLY --steps steps between barrier + synchronize, MAX over ranks
+        if rep == ev_repeats and rank == 0:
+            ev_stash, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+            if args.model == 1 and not args.no_events and getattr(enc, "hip_convs", None):
+                rn_records = crw_hip.rn_timing_read()
+                crw_hip.rn_timing(False)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
@@ -555,6 +654,11 @@ def main():
         rep_elapsed.append(el)
     elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]  # the median repeat is the one reported
     final_loss = loss.item()
+    if rank == 0 and ev_stash is None:
+        ev_stash, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+        if args.model == 1 and not args.no_events and getattr(enc, "hip_convs", None):
+            rn_records = crw_hip.rn_timing_read()
+            crw_hip.rn_timing(False)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -562,9 +666,11 @@ def main():
             "metric": "radargram columns/sec (CRW fwd+bwd)", "value": cols_per_step * world / (elapsed / args.steps),
             "unit": "radargram columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "repeats": {"n": len(rep_elapsed), "what": "value / ms_per_step are the median of n timed regions of `steps` steps each",
+            "repeats": {"n": len(rep_elapsed), "what": "value / ms_per_step are the median of n timed regions of `steps` steps each "
+                                                       "(n sized to keep the GPU busy for about --gpu-seconds unless --repeats is given)",
+                        "gpu_busy_s": sum(rep_elapsed),
                         "ms_per_step_min": min(rep_elapsed) / args.steps * 1e3, "ms_per_step_max": max(rep_elapsed) / args.steps * 1e3,
-                        "ms_per_step_all": [e / args.steps * 1e3 for e in rep_elapsed]},
+                        "ms_per_step_all": [round(e / args.steps * 1e3, 4) for e in rep_elapsed]},
             "dtype": {"bf16x3": "f32 (conv2-5 multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; everything else fp32)",
                       "bf16": "bf16 (conv2-5 operands, fp32 accumulate), f32 elsewhere", "torch": "f32",
                       "resnet": "f32 (every convolution and the linear head multiply on the bf16 matrix cores with hi/lo operand pairs, fp32 accumulate: fp32-grade; "
@@ -579,17 +685,16 @@ def main():
                        "encoder_convs": args.convs if (args.model == 0 or args.convs == "torch") else "bf16x3 (resnet_hip)", "loss": final_loss},
         }
         kernels = []
-        if args.model == 1 and not args.no_events and getattr(enc, "hip_convs", None):
-            crw_hip.KERNEL_EVENTS = None
+        if rn_records is not None:
             ev = {}
-            for rec in crw_hip.rn_timing_read():
+            for rec in rn_records:
                 key = ("rn_conv" if rec.kind == 0 else "rn_wgrad", rec.mode, *list(rec.g), rec.k, rec.stride, rec.pad)
                 ev.setdefault(key, []).append(rec.ms)
-            crw_hip.rn_timing(False)
-            kernels = resnet_event_kernels(ev, B * T * N, args.steps * max(1, args.repeats))
-        if crw_hip.KERNEL_EVENTS:
-            # per-kernel durations measured live over the timed region (HIP events on the launch stream)
-            ev, crw_hip.KERNEL_EVENTS = crw_hip.KERNEL_EVENTS, None
+            kernels = resnet_event_kernels(ev, B * T * N, args.steps * ev_repeats)
+            ev_stash = None
+        if ev_stash:
+            # per-kernel durations measured live over the timed region (HIP events on the launch stream; first `ev_repeats` repeats)
+            ev = ev_stash
             split = 3 if args.convs == "bf16x3" else 1
             P = B * T * N
             mpx = (PATCH[0] - 6) * (PATCH[1] - 6)  # pixels of the conv3-5 feature map (100 for 16 x 16 patches)
@@ -617,7 +722,7 @@ def main():
                                 "unit": "TFLOP/s", "frac": alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
                                 "mfma_executed_tflops": alg * split * pad / (kms * 1e-3) / 1e12,
                                 "mfma_executed_frac": alg * split * pad / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                                "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // (args.steps * max(1, args.repeats)),
+                                "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // (args.steps * ev_repeats),
                                 "timed_launches": len(pairs),
                                 "note": "achieved = algorithmic (fp32-equivalent) flops / mean HIP-event time of this kernel's "
                                         "launches INSIDE the timed steps (events recorded on the launch stream); "

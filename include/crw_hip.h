@@ -21,8 +21,12 @@
  *   - tensors are dense row-major fp32 with the shapes given per function;
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); nothing synchronises;
  *   - no allocation inside: workspaces are sized with the crw_*_bytes() queries and passed in;
- *   - return value: CRW_OK or an error code; nothing is thrown across the ABI; the library is
- *     stateless and thread-safe (one caller per stream).
+ *   - return value: CRW_OK or an error code; nothing is thrown across the ABI;
+ *   - Threads: the kernels' entry points keep no state between calls and may be called from any thread (one caller per stream).
+ *     Two corners do keep state: crw_rn_train_fwd / crw_rn_train_bwd / crw_rn_eval_fwd order part of their work on one internal
+ *     side stream PER DEVICE (created on first use, with its event pool) -- at most one host thread per device may be inside them
+ *     at a time; and the crw_rn_timing_* diagnostic (one global record list).  Everything they enqueue on the side stream is joined
+ *     back into the caller's stream before they return, on error paths too.
  */
 #ifndef CRW_HIP_H
 #define CRW_HIP_H

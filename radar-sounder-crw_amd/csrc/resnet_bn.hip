@@ -176,15 +176,17 @@ struct BwdTail {  // backward: sums (g, g xhat [, g xhat_d]) -> dbeta, dgamma [,
 
 // Hand-off between the blocks of a channel block, in the terms of the HIP memory model: every thread's partial-sum stores
 // happen-before the block barrier, the barrier happens-before thread 0's ticket fetch_add, which is a RELEASE at agent scope; the
-// block that draws the last ticket did so with an ACQUIRE (acq_rel on the same atomic), so its fetch_add synchronizes-with every
-// earlier one, and its barrier orders the other threads' loads behind it.  On gfx950 the release is one L2 write-back request + wait
-// per BLOCK (the partial sums are written through by their sc1 stores, so it finds nothing of ours to write), the acquire one
-// L1 / L2 invalidate in the one block that goes on.  `relaxed` (CRW_RN_TICKET_RELAXED=1, A/B only) is the round-3 form: relaxed
-// atomics behind s_waitcnt vmcnt(0) -- correct on this chip because the sc1 stores are acknowledged by the memory side before the
-// ticket is drawn and the sc1 loads bypass the non-coherent caches, but outside the language's model.
+// block that reads the last ticket from it then executes an ACQUIRE fence at agent scope -- a fence after an atomic read that took
+// its value from a release sequence synchronizes with every release in it -- and its barrier orders the other threads' loads behind
+// the fence.  On gfx950 the release is one L2 write-back request + wait per BLOCK (the partial sums are written through by their
+// sc1 stores, so it finds nothing of ours to write), the acquire one L1 / L2 invalidate in the ONE block per channel block that goes
+// on (an acq_rel fetch_add would invalidate in every block and take the other kernels' L2 contents with it: mode 2, measured).
+// mode (CRW_RN_TICKET, A/B only): 0 = this; 1 = "relaxed", the round-3 form -- relaxed atomics behind s_waitcnt vmcnt(0): it works on
+// this chip because the sc1 stores are acknowledged by the memory side before the ticket is drawn and the sc1 loads bypass the
+// non-coherent caches, but it is outside the language's model; 2 = "acqrel" on the fetch_add.
 template <int NS, bool INTERLEAVED, class Tail>
 __global__ __launch_bounds__(1024) void rn_sums_tail_kernel(const float *__restrict__ in, int R, int C, int RB, double *part2,
-                                                            unsigned *tickets, int relaxed, Tail tail) {
+                                                            unsigned *tickets, int mode, Tail tail) {
   __shared__ double sh[NS][16][64];
   __shared__ unsigned ticket;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -210,11 +212,18 @@ __global__ __launch_bounds__(1024) void rn_sums_tail_kernel(const float *__restr
     // XCD's L2 back once per wave: measured +0.8 ms per step.)
     __hip_atomic_store(&part2[((long)blockIdx.y * NS + rl) * C + c], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (relaxed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been acknowledged ...
-  __syncthreads();                                                // ... for every wave of the block, before its ticket is drawn
-  if (threadIdx.x == 0)
-    ticket = relaxed ? __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                     : __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (mode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been acknowledged ...
+  __syncthreads();                                                  // ... for every wave of the block, before its ticket is drawn
+  if (threadIdx.x == 0) {
+    unsigned t;
+    if (mode == 1) t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (mode == 2) t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gridDim.y - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    ticket = t;
+  }
   __syncthreads();
   if (ticket != gridDim.y - 1) return;
   const int R2 = gridDim.y;
@@ -884,12 +893,15 @@ inline unsigned grid_for(long n, int per_block = 256, long cap = 8192) {
 template <int NS, bool INTERLEAVED, class Tail>
 int rn_sums_tail(const float *in, int R, int C, double *part2, unsigned *tickets, const Tail &tail, hipStream_t s) {
   if ((C + 63) / 64 > RN_TICKET_BLOCKS || !tickets) return CRW_EINVAL;
-  static const int relaxed = (getenv("CRW_RN_TICKET_RELAXED") && getenv("CRW_RN_TICKET_RELAXED")[0] == '1') ? 1 : 0;
+  static const int mode = [] {
+    const char *e = getenv("CRW_RN_TICKET");
+    return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'a' ? 2 : 0));  // "relaxed" | "acqrel" (A/B); default: release + acquire fence
+  }();
   const int want = NS * C >= 256 ? 32 : 64;
   const int RB = (R + want - 1) / want > 0 ? (R + want - 1) / want : 1;
   const int R2 = (R + RB - 1) / RB;
   hipLaunchKernelGGL((rn_sums_tail_kernel<NS, INTERLEAVED, Tail>), dim3((C + 63) / 64, R2), dim3(1024), 0, s, in, R, C, RB, part2, tickets,
-                     relaxed, tail);
+                     mode, tail);
   return check_launch();
 }
 

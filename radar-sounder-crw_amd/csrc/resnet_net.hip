@@ -239,7 +239,17 @@ struct SideStream {
     hipEvent_t e = event();
     return e && hipEventRecord(e, from) == hipSuccess && hipStreamWaitEvent(to, e, 0) == hipSuccess;
   }
-} g_side;
+};
+// One side stream (and event pool) per DEVICE, created on first use while that device is current -- a process that drives several
+// GPUs gets a stream on each.  The pools are not locked: ONE host thread per device may be inside crw_rn_train_* / crw_rn_eval_fwd
+// at a time (include/crw_hip.h, "Threads").
+constexpr int MAX_DEVICES = 64;
+SideStream g_sides[MAX_DEVICES];
+SideStream &side_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  return g_sides[dev];
+}
 
 // k = kh * 256 + kw for a kernel that is not square (the head over an hl x wl map), else the side
 int conv(hipStream_t s, int mode, int P, int Hs, int Ws, int Cs, int Hd, int Wd, int N, int k, int stride, int pad, Planes a, const uint16_t *bh,
@@ -269,9 +279,10 @@ int wgrad(hipStream_t s, int mode, int P, int Hin, int Win, int Cin, int Hout, i
 // Whatever a pass has put on the side stream is joined back into the caller's stream on EVERY exit, error paths included: the caller
 // frees / re-uses the workspace and the gradient buffer in stream order of ITS stream.
 struct SideJoin {
+  SideStream &side;
   hipStream_t s, sw;
   ~SideJoin() {
-    if (sw != s && !g_side.order(sw, s)) (void)hipStreamSynchronize(sw);
+    if (sw != s && !side.order(sw, s)) (void)hipStreamSynchronize(sw);
   }
 };
 
@@ -298,12 +309,13 @@ int forward_pass(bool training, const float *x, int P, int cin, int h, int w, co
   // side stream: the weight packing runs beside the stem (which does not need it), each shortcut convolution + its statistics
   // beside its block's main branch (CRW_RN_STREAMS=0: everything on the caller's stream)
   static const bool use_side = !(getenv("CRW_RN_STREAMS") && getenv("CRW_RN_STREAMS")[0] == '0');
+  SideStream &g_side = side_of_current_device();
   hipStream_t sw = use_side ? g_side.get() : nullptr;
   if (!sw) sw = s;
   g_side.used = 0;
   auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };
   auto join = [&]() { return sw == s || g_side.order(sw, s) ? CRW_OK : CRW_EHIP; };
-  SideJoin guard{s, sw};
+  SideJoin guard{g_side, s, sw};
   CRW_TRY(rn_zero_tickets(pl.tickets, 2, s));
 
   // all convolution / linear weights -> hi / lo planes (forward and backward-data layouts), one launch
@@ -424,11 +436,12 @@ int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, i
   hipStream_t s = (hipStream_t)stream;
   // weight gradients on the side stream (CRW_RN_STREAMS=0: everything on the caller's stream)
   static const bool use_side = !(getenv("CRW_RN_STREAMS") && getenv("CRW_RN_STREAMS")[0] == '0');
+  SideStream &g_side = side_of_current_device();
   hipStream_t sw = use_side ? g_side.get() : nullptr;
   if (!sw) sw = s;
   g_side.used = 0;
   auto fork = [&]() { return sw == s || g_side.order(s, sw) ? CRW_OK : CRW_EHIP; };  // side stream sees what the chain has produced
-  SideJoin guard{s, sw};  // error paths included: the caller's stream waits for whatever the side stream still holds
+  SideJoin guard{g_side, s, sw};  // error paths included: the caller's stream waits for whatever the side stream still holds
   CRW_TRY(rn_zero_tickets(pl.tickets, 2, s));
 
   // head (one product over layer4's hl x wl map, see Plan): per-pixel weight gradients, then their mean = fc.weight's gradient
