@@ -164,7 +164,17 @@ constexpr int ring_stages() {
 template <int SPLIT, int TB>
 constexpr size_t ring_bytes() { return (size_t)ring_stages<SPLIT, TB>() * ((SPLIT == 3) ? 4 : 2) * TB * 2 * tile_bk<SPLIT, TB>(); }
 
-template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA>
+// DIAG (tools/ubench/gemm_ceiling.hip only; the library instantiates DIAG = 0): timing-only variants of this loop that leave parts
+// of it out, so that what each part costs can be read off on the chip -- results are meaningless.
+//   1 = MFMAs alone (fragments read once, before the loop)      2 = + the LDS fragment reads of every k-step
+//   3 = + the barrier (and its waits) per k-tile                 4 = + the LDS-DMA stream: the whole loop (= 0)
+//   5 = the LDS-DMA stream alone with its waits (no reads, no MFMAs, no barrier)      6 = DMA stream + barrier
+constexpr bool diag_dma(int d) { return d == 0 || d >= 4; }
+constexpr bool diag_barrier(int d) { return d == 0 || d == 3 || d == 4 || d == 6; }
+constexpr bool diag_reads(int d) { return d == 0 || (d >= 2 && d <= 4); }
+constexpr bool diag_mfma(int d) { return d <= 4; }
+
+template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA, int DIAG = 0>
 __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0,
                                 int n0, char *lds, int wave, int lane) {
   using C = Cfg<TB>;
@@ -198,21 +208,39 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
   } else {
     for (int t = 0; t < NSTAGE - 1 && t < nt; ++t) stage(t, t);
   }
+  // (DIAG builds without the DMA stream or without fragment reads in the loop: both buffers hold real tiles, fragments of tile 0)
+  bf8 dg_b[C::FN], dg_bl[C::FN], dg_a[4], dg_al[4];
+  if constexpr (DIAG != 0) {
+    if (nt > 1 && NSTAGE == 2) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int j = 0; j < C::FN; ++j) {
+      dg_b[j] = read_frag<BKC, TB, BKB, IMG>(lds, wn + 16 * j, 0, lane);
+      dg_bl[j] = dg_b[j];
+    }
+    for (int i = 0; i < 4; ++i) {
+      dg_a[i] = read_frag<AKC, TB, BKB, 0>(lds, wm + 16 * i, 0, lane);
+      dg_al[i] = dg_a[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   for (int t = 0; t < nt; ++t) {
-    if (t + 2 < nt && NSTAGE >= 4)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-    else if (t + 1 < nt && NSTAGE >= 3)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1) % NSTAGE is free
+    if constexpr (diag_dma(DIAG)) {
+      if (t + 2 < nt && NSTAGE >= 4)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      else if (t + 1 < nt && NSTAGE >= 3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (diag_barrier(DIAG)) __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1) % NSTAGE is free
     if constexpr (REGA) {
       if (t + 1 < nt) {
         load_image_regs<AKC, TB, C::WAVES, BKB>(A.hi, n, m0, (t + 1) * BKB, wave, lane, ra);
         stage_image<BKC, TB, C::WAVES, BKB>(B.hi, n, n0, (t + 1) * BKB, lds + ((t + 1) & 1) * NIMG * IMG + IMG, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {
+    } else if constexpr (diag_dma(DIAG)) {
       if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
     }
     const char *base = lds + (t % NSTAGE) * NIMG * IMG;
@@ -224,31 +252,48 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
       bf8 b[C::FN], bl[C::FN];
 #pragma unroll
       for (int j = 0; j < C::FN; ++j) {
-        b[j] = read_frag<BKC, TB, BKB, IMG>(base, wn + 16 * j, s, lane);
-        if constexpr (SPLIT == 3) bl[j] = read_frag<BKC, TB, BKB, 3 * IMG>(base, wn + 16 * j, s, lane);
+        if constexpr (diag_reads(DIAG)) {
+          b[j] = read_frag<BKC, TB, BKB, IMG>(base, wn + 16 * j, s, lane);
+          if constexpr (SPLIT == 3) bl[j] = read_frag<BKC, TB, BKB, 3 * IMG>(base, wn + 16 * j, s, lane);
+        } else {
+          b[j] = dg_b[j];
+          bl[j] = dg_bl[j];
+        }
       }
 #pragma unroll
       for (int i0 = 0; i0 < C::FM; i0 += AG) {
         bf8 a[AG], al[AG];
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
-          a[i] = read_frag<AKC, TB, BKB, 0>(base, wm + 16 * (i0 + i), s, lane);
-          if constexpr (SPLIT == 3) al[i] = read_frag<AKC, TB, BKB, 2 * IMG>(base, wm + 16 * (i0 + i), s, lane);
+          if constexpr (diag_reads(DIAG)) {
+            a[i] = read_frag<AKC, TB, BKB, 0>(base, wm + 16 * (i0 + i), s, lane);
+            if constexpr (SPLIT == 3) al[i] = read_frag<AKC, TB, BKB, 2 * IMG>(base, wm + 16 * (i0 + i), s, lane);
+          } else {
+            a[i] = dg_a[i];
+            al[i] = dg_al[i];
+          }
         }
-        if (!AKC || !BKC) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
+        if ((!AKC || !BKC) && diag_reads(DIAG)) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (diag_mfma(DIAG)) {
 #pragma unroll
-        for (int i = 0; i < AG; ++i)
+          for (int i = 0; i < AG; ++i)
 #pragma unroll
-          for (int j = 0; j < C::FN; ++j) {
-            if (SPLIT == 3) {
-              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i0 + i][j], 0, 0, 0);
-              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+            for (int j = 0; j < C::FN; ++j) {
+              if (SPLIT == 3) {
+                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i0 + i][j], 0, 0, 0);
+                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+              }
+              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i0 + i][j], 0, 0, 0);
             }
-            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i0 + i][j], 0, 0, 0);
-          }
+        } else if constexpr (diag_reads(DIAG)) {  // (no MFMAs: keep the fragment reads alive)
+#pragma unroll
+          for (int i = 0; i < AG; ++i) asm volatile("" ::"v"(a[i]), "v"(al[i]));
+#pragma unroll
+          for (int j = 0; j < C::FN; ++j) asm volatile("" ::"v"(b[j]), "v"(bl[j]));
+        }
       }
     }
     if constexpr (REGA) {
@@ -267,7 +312,7 @@ __device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uin
 
 // One kernel per operand layout (AKC, BKC): a run-time switch over the four main loops costs ~70
 // VGPRs and spills the 256x256 configuration.  The launcher groups products by layout.
-template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA>
+template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA, int DIAG = 0>
 __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(GemmGroup g) {
   using C = Cfg<TB>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -308,7 +353,7 @@ __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(Gemm
     const long sA = prod ? p.sA2 : p.sA, sB = prod ? p.sB2 : p.sB;
     BfOperand A{Ah + b * sA, (const uint16_t *)(prod ? p.A2l : p.Al) + b * sA};
     BfOperand B{(const uint16_t *)(prod ? p.B2 : p.B) + b * sB, (const uint16_t *)(prod ? p.B2l : p.Bl) + b * sB};
-    mainloop<SPLIT, TB, AKC, BKC, REGA>(acc, A, B, n, m0, n0, lds, wave, lane);
+    mainloop<SPLIT, TB, AKC, BKC, REGA, DIAG>(acc, A, B, n, m0, n0, lds, wave, lane);
   }
 
   const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
@@ -338,12 +383,12 @@ __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(Gemm
     }
 }
 
-template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA = false>
+template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA = false, int DIAG = 0>
 int launch_one(const GemmGroup &g, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = ring_bytes<SPLIT, TB>();
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA>,
+    if (hipFuncSetAttribute((const void *)gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA, DIAG>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
@@ -351,7 +396,7 @@ int launch_one(const GemmGroup &g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = g.n / TB;
-  hipLaunchKernelGGL((gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA>), dim3(tiles * tiles, g.batch, g.nprob),
+  hipLaunchKernelGGL((gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA, DIAG>), dim3(tiles * tiles, g.batch, g.nprob),
                      dim3(Cfg<TB>::WAVES * 64), lds, s, g);
   return check_launch();
 }

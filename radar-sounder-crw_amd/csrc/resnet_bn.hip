@@ -8,6 +8,7 @@
 // every plane (the GEMM epilogues then need no row predicate and the padded rows add nothing to any statistic).
 // A BatchNorm's coefficients travel as coef[4][C] = (scale = gamma * invstd, shift = beta - mean * scale, mean, invstd).
 #include "crw_common.h"
+#include <algorithm>
 #include <atomic>
 #include "resnet.h"
 
@@ -765,23 +766,54 @@ __global__ __launch_bounds__(256) void rn_pack_conv_kernel(const float *__restri
 }
 
 // every convolution / linear weight of the network in ONE launch (12 launches of the kernel above were 115 us of a 5.5 ms
-// step): block = one output channel of one layer -- its cin * T source values are contiguous, read 16 bytes per lane
+// step).  Block = 8 output channels x one chunk of input channels of one layer, staged through LDS so that BOTH layouts leave in
+// 16-byte pieces: the forward planes [co][t][ci] as 8 consecutive ci, the backward planes [ci][t][co] as the block's 8 co.  (The
+// first version -- a block per output channel, one 2-byte store per element and plane -- wrote 318 MB per step for 40 MB of
+// planes: every backward-plane store touched its own 32-byte sector; PMC, profiles/r03_pmc_resnet.json.)
+constexpr int RN_PACK_CO = 8;
+__device__ inline int rn_pack_ci_chunk(int T) { return T <= 16 ? 64 : 8; }  // 8 * chunk * T floats of LDS: at most 32 KB (T <= 64)
 __global__ __launch_bounds__(256) void rn_pack_all_kernel(RnPackJobs jobs) {
+  extern __shared__ float pv[];  // [8 co][chunk ci][T]
   int j = 0;
   while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
   const RnPackJob &q = jobs.job[j];
-  const int co = blockIdx.x - q.first_block;
-  const int n = q.cin * q.T;
-  const float *src = q.w + (long)co * (q.bcast ? q.cin : n);
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int ci = e / q.T, t = e - ci * q.T;
-    const float v = q.bcast ? src[ci] * q.scale : src[e];
-    const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
-    const long f = ((long)co * q.T + t) * q.cin + ci, b = ((long)ci * q.T + t) * q.cout + co;
-    q.fh[f] = h;
-    q.fl[f] = l;
-    q.bh[b] = h;
-    q.bl[b] = l;
+  const int T = q.T, cb = rn_pack_ci_chunk(T), ncc = q.cin / cb;
+  const int local = blockIdx.x - q.first_block;
+  const int co0 = (local / ncc) * RN_PACK_CO, ci0 = (local % ncc) * cb;
+  const int row = cb * T;  // values of one output channel in this chunk: contiguous in the source (ci-major, tap-minor)
+  for (int idx = threadIdx.x; idx < RN_PACK_CO * row; idx += 256) {
+    const int r = idx / row, e = idx - r * row;
+    pv[idx] = q.bcast ? q.w[(long)(co0 + r) * q.cin + ci0 + e / T] * q.scale : q.w[((long)(co0 + r) * q.cin + ci0) * T + e];
+  }
+  __syncthreads();
+  // forward planes: (co, t) rows of q.cin values; this block holds cb of them per row = cb / 8 pieces of 16 bytes
+  for (int task = threadIdx.x; task < RN_PACK_CO * T * (cb / 8); task += 256) {
+    const int c8 = task % (cb / 8), t = (task / (cb / 8)) % T, r = task / ((cb / 8) * T);
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const float v0 = pv[r * row + (c8 * 8 + k) * T + t], v1 = pv[r * row + (c8 * 8 + k + 1) * T + t];
+      const uint16_t h0 = f2bf(v0), h1 = f2bf(v1);
+      h[k / 2] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      l[k / 2] = (uint32_t)f2bf(v0 - bf2f(h0)) | ((uint32_t)f2bf(v1 - bf2f(h1)) << 16);
+    }
+    const long f = ((long)(co0 + r) * T + t) * q.cin + ci0 + c8 * 8;
+    *reinterpret_cast<uint4 *>(q.fh + f) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4 *>(q.fl + f) = uint4{l[0], l[1], l[2], l[3]};
+  }
+  // backward planes: (ci, t) rows of q.cout values; this block holds its 8 output channels of each = one piece of 16 bytes
+  for (int task = threadIdx.x; task < row; task += 256) {  // task = ci_local * T + t, the source order
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const float v0 = pv[k * row + task], v1 = pv[(k + 1) * row + task];
+      const uint16_t h0 = f2bf(v0), h1 = f2bf(v1);
+      h[k / 2] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      l[k / 2] = (uint32_t)f2bf(v0 - bf2f(h0)) | ((uint32_t)f2bf(v1 - bf2f(h1)) << 16);
+    }
+    const long b = ((long)ci0 * T + task) * q.cout + co0;
+    *reinterpret_cast<uint4 *>(q.bh + b) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4 *>(q.bl + b) = uint4{l[0], l[1], l[2], l[3]};
   }
 }
 
@@ -1071,13 +1103,19 @@ int launch_rn_pack_conv(const float *w, int cout, int cin, int T, uint16_t *fh, 
 }
 
 int launch_rn_pack_all(RnPackJobs &jobs, hipStream_t s) {
-  int blocks = 0;
-  for (int i = 0; i < jobs.n; ++i) {
-    jobs.job[i].first_block = blocks;
-    blocks += jobs.job[i].cout;
-  }
   if (jobs.n < 1 || jobs.n > RN_MAX_PACK_JOBS) return CRW_EINVAL;
-  hipLaunchKernelGGL(rn_pack_all_kernel, dim3(blocks), dim3(256), 0, s, jobs);
+  int blocks = 0;
+  size_t lds = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    RnPackJob &q = jobs.job[i];
+    const int cb = q.T <= 16 ? 64 : 8;
+    if (q.T < 1 || q.T > 64 || q.cout % RN_PACK_CO || q.cin % cb || (((uintptr_t)q.fh | (uintptr_t)q.fl | (uintptr_t)q.bh | (uintptr_t)q.bl) & 15))
+      return CRW_EINVAL;
+    q.first_block = blocks;
+    blocks += (q.cout / RN_PACK_CO) * (q.cin / cb);
+    lds = std::max(lds, (size_t)RN_PACK_CO * cb * q.T * sizeof(float));
+  }
+  hipLaunchKernelGGL(rn_pack_all_kernel, dim3(blocks), dim3(256), lds, s, jobs);
   return check_launch();
 }
 
