@@ -29,11 +29,12 @@ class _HipEncoder(torch.autograd.Function):
     and the front end's record (pool1 planes + pooling codes), from which its backward kernel runs without recomputation."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, split):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, split, bwd_split=None):
         import crw_hip
         x = x.contiguous()
         w2p = crw_hip.enc_front_pack(w2, split)
         packed = [crw_hip.enc_pack_weights(w, split) for w in (w3, w4, w5)]
+        ctx.bwd_split = bwd_split or split  # "mixed": forward on hi/lo pairs, backward on the hi planes alone
         # the front end also keeps its pool1 planes and pooling codes (10 KB per patch): its backward kernel then skips the
         # conv1 -> pool1 -> conv2 recomputation
         x3h, x3l, fsaved = crw_hip.enc_front_fwd(split, x, w1, b1, w2p[:2], b2, save=True)
@@ -51,7 +52,7 @@ class _HipEncoder(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dgap):
         import crw_hip
-        s = ctx.split
+        s = ctx.bwd_split
         if ctx.needs_input_grad[0]:
             raise RuntimeError("the fused HIP encoder does not produce a gradient for its input patches (the reference never "
                                "asks for one); set CNN.hip_convs = None to differentiate with respect to the input")
@@ -61,6 +62,10 @@ class _HipEncoder(torch.autograd.Function):
         x3h, x3l, y3h, y3l, y4h, y4l, y5h = sv[8:15]
         bwd_w = [(sv[15], sv[16]), (sv[17], sv[18]), (sv[19], sv[20])]
         fsaved = sv[21]
+        if s == 1:  # the plain-bf16 kernels read the hi planes only
+            x3l = y3l = y4l = None
+            bwd_w = [(h, None) for h, _ in bwd_w]
+            w2p = (w2p[0], None, w2p[2], None)
         # dY5 = dgap/100 gated by y5 > 0 (ReLU5 + GAP backward) is built inside the two kernels' loaders
         dgap = dgap.contiguous().float()
         dw5, db5 = crw_hip.enc_wgrad(s, y5h, None, y4h, y4l, dgap=dgap)
@@ -70,7 +75,7 @@ class _HipEncoder(torch.autograd.Function):
         dw3, db3 = crw_hip.enc_wgrad(s, d3h, d3l, x3h, x3l)
         _, _, dx3, _ = crw_hip.enc_conv3x3(1, s, d3h, d3l, *bwd_w[0], 32, planes=False, f32=True)  # [P,100,32]
         dw1, db1, dw2, db2 = crw_hip.enc_front_bwd(s, x, w1, b1, w2p[:2], b2, w2p[2:], dx3, saved=fsaved)
-        return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None
+        return None, dw1, db1, dw2, db2, dw3, db3, dw4, db4, dw5, db5, None, None
 
 class _HipMapEncoder(torch.autograd.Function):
     """The whole conv trunk of ``CNN`` on patches of ANY size (training at patch sizes other than 16x16, e.g. the 32x32
@@ -165,14 +170,17 @@ class CNN(nn.Module):
         self.global_avg_pool = nn.AdaptiveAvgPool2d(1)
         self.fc = nn.Linear(cin, FEATURE_DIM)
         self.num_params = _report(self)
-        self.hip_convs = "bf16x3"  # "bf16x3" | "bf16" | None (PyTorch ops); only used on an MI355X
+        # "bf16x3" (default): hi/lo bf16 operand pairs, fp32-grade forward AND backward | "mixed" (opt-in, 16x16 patches): the same
+        # forward, backward on the hi planes alone (plain bf16 operands, fp32 accumulate: gradients to ~1e-2) | "bf16": plain bf16
+        # operands both ways | None: PyTorch ops.  Only used on an MI355X
+        self.hip_convs = "bf16x3"
 
     def forward(self, x):
         if self.hip_convs and x.is_cuda and x.shape[-2:] == (16, 16) and x.dtype == torch.float32:
             c = [getattr(self, "conv%d" % i) for i in range(1, 6)]
             gap = _HipEncoder.apply(x, c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[2].weight, c[2].bias,
                                     c[3].weight, c[3].bias, c[4].weight, c[4].bias,
-                                    3 if self.hip_convs == "bf16x3" else 1)
+                                    3 if self.hip_convs in ("bf16x3", "mixed") else 1, 1 if self.hip_convs == "mixed" else None)
             return self._head(gap)
         if self.hip_convs and x.is_cuda and x.dtype == torch.float32 and min(x.shape[-2:]) >= 7:
             if not torch.is_grad_enabled():
@@ -181,7 +189,7 @@ class CNN(nn.Module):
             c = [getattr(self, "conv%d" % i) for i in range(1, 6)]
             gap = _HipMapEncoder.apply(x, c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[2].weight, c[2].bias,
                                        c[3].weight, c[3].bias, c[4].weight, c[4].bias,
-                                       3 if self.hip_convs == "bf16x3" else 1)
+                                       3 if self.hip_convs in ("bf16x3", "mixed") else 1)
             return self._head(gap)
         if self.hip_convs and x.is_cuda and not CNN._warned_fallback:
             # not silent: the caller believes it is on the hand-written kernels (set hip_convs = None to choose this path)
@@ -207,7 +215,7 @@ class CNN(nn.Module):
         tiles over the feature map.
         x [P,cin,h,w] -> pooled features [P,128]."""
         import crw_hip
-        split = 3 if self.hip_convs == "bf16x3" else 1
+        split = 3 if self.hip_convs in ("bf16x3", "mixed") else 1
         P, _, h, w = x.shape
         H, W = h - 6, w - 6  # conv3-5 feature map
         w2p = crw_hip.enc_front_pack(self.conv2.weight, split)
