@@ -943,9 +943,13 @@ __global__ __launch_bounds__(NTH) void front_bwd_tile_kernel(FrontBwdArgs a) {
           for (int r = 0; r < 4; ++r) dacc[r] += __shfl_down(dacc[r], 8, 64) + dacc1[r];
         }
         if (r16 < 8) {
+          // (opaque to the compiler: it would hoist the four rows' positions and LDS addresses out of the unit loop and, at the
+          // 128-register cap of a 1024-thread workgroup, park them in scratch -- reloaded with an exposed latency each)
+          int gq = g;
+          asm volatile("" : "+v"(gq));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 4 * g + r;
+            const int row = 4 * gq + r;
             const int x = (row >= 4 && row < 12) ? row - 4 : (row < 4 ? 8 + row : min(row, TAW - 1));
             const int ay = oy0 + wave - 1, ax = ox0 + x - 1;
             const bool ok = ay >= 0 && ay < H - 3 && ax >= 0 && ax < W - 3;
@@ -970,17 +974,22 @@ __global__ __launch_bounds__(NTH) void front_bwd_tile_kernel(FrontBwdArgs a) {
       const int rp = tid % nrp, q = tid / nrp, ty = q % 5, ci = (q / 5) % cin, co = q / (5 * cin);
       for (int y = rp; y < TCW; y += nrp) {
         const float *dr = dC1 + co * TCN + y * TCW, *xr = L.xs + (ci * TXW + y + ty) * TXW;
-        float dv[TCW], xv[TXW];
+        // two halves of the pixel row: 8 + 12 values live at a time instead of 16 + 20 (the whole row at once put this kernel
+        // 84 bytes per lane into scratch at its 128-register cap)
+#pragma unroll 1
+        for (int h = 0; h < TCW; h += TCW / 2) {
+          float dv[TCW / 2], xv[TCW / 2 + 4];
 #pragma unroll
-        for (int x = 0; x < TCW; ++x) dv[x] = dr[x];
+          for (int x = 0; x < TCW / 2; ++x) dv[x] = dr[h + x];
 #pragma unroll
-        for (int x = 0; x < TXW; ++x) xv[x] = xr[x];
+          for (int x = 0; x < TCW / 2 + 4; ++x) xv[x] = xr[h + x];
 #pragma unroll
-        for (int tx = 0; tx < 5; ++tx) {
-          float s1 = 0.f;
+          for (int tx = 0; tx < 5; ++tx) {
+            float s1 = 0.f;
 #pragma unroll
-          for (int x = 0; x < TCW; ++x) s1 = fmaf(dv[x], xv[x + tx], s1);
-          dw1[tx] += s1;
+            for (int x = 0; x < TCW / 2; ++x) s1 = fmaf(dv[x], xv[x + tx], s1);
+            dw1[tx] += s1;
+          }
         }
       }
     }

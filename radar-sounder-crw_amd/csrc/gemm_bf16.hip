@@ -307,13 +307,78 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
   __syncthreads();  // the second product (or the next use of LDS) may restage buffer 0
 }
 
+// ---- 256 x 256, plain bf16: ring of FIVE 32-deep half-tiles, one barrier per PAIR of them ---------------------------------------
+// tools/ubench/gemm_ceiling.hip (profiles/r04_gemm_ceiling.log) on the two-stage ring above: MFMAs + fragment reads + barrier take
+// 1.46 us per 64-deep k-tile and CU, the LDS-DMA stream ALONE 1.12 us (58 GB/s per CU) -- but the stream WITH the barrier 1.73 us:
+// with two 64 KiB stages, tile t+1 can only be requested once every wave has left tile t-1 (the barrier) and must have landed by
+// the next barrier, so every k-tile pays the full issue + landing latency of its 64 KiB, and 160 KiB of LDS hold no third stage.
+// Here the same 64-deep tile is two half-tiles of 32 KiB in a ring of five: at barrier t the pair (2t, 2t+1) has landed, half 2t+2
+// is already in flight (requested one barrier earlier), and the two buffers the barrier frees take halves 2t+3 and 2t+4.  Every
+// half gets a whole period (or two) to land, 96 KiB are in flight instead of 64, and the barrier count stays one per 64 deep
+// (round 2's 5-stage ring of 32-deep tiles paid a barrier per 32 and lost).  LDS: 5 x 32 KiB = all 160 KiB of the CU.
+template <int TB, bool AKC, bool BKC, int DIAG = 0>
+__device__ inline void mainloop_ring5(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0, int n0, char *lds,
+                                      int wave, int lane) {
+  using C = Cfg<TB>;
+  constexpr int BKB = 32, IMG = TB * 2 * BKB, STG = 2 * IMG, NST = 5;
+  constexpr int GH = (TB * BKB / 512 / C::WAVES) * 2;  // LDS-DMA instructions per wave and half-tile
+  const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
+  const int nh = n / BKB;  // half-tiles (even: n is a multiple of 256)
+  auto stage = [&](int h) {
+    char *base = lds + (h % NST) * STG;
+    stage_image<AKC, TB, C::WAVES, BKB>(A.hi, n, m0, h * BKB, base, wave, lane);
+    stage_image<BKC, TB, C::WAVES, BKB>(B.hi, n, n0, h * BKB, base + IMG, wave, lane);
+  };
+  for (int h = 0; h < 3 && h < nh; ++h) stage(h);
+  for (int t = 0; 2 * t < nh; ++t) {
+    if (2 * t + 2 < nh) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GH) : "memory");  // all but the youngest half (2t+2) have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ... for every wave; the buffers of halves 2t-2 and 2t-1 are free
+    if constexpr (DIAG == 0 || DIAG >= 4) {
+      if (2 * t + 3 < nh) stage(2 * t + 3);
+      if (2 * t + 4 < nh) stage(2 * t + 4);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const char *base = lds + ((2 * t + hh) % NST) * STG;
+      constexpr int AG = 4;
+      bf8 b[C::FN];
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) b[j] = read_frag<BKC, TB, BKB, IMG>(base, wn + 16 * j, 0, lane);
+#pragma unroll
+      for (int i0 = 0; i0 < C::FM; i0 += AG) {
+        bf8 a[AG];
+#pragma unroll
+        for (int i = 0; i < AG; ++i) a[i] = read_frag<AKC, TB, BKB, 0>(base, wm + 16 * (i0 + i), 0, lane);
+        if (!AKC || !BKC) {  // inline-asm reads are invisible to the compiler's lgkmcnt bookkeeping
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (DIAG <= 4) {
+#pragma unroll
+          for (int i = 0; i < AG; ++i)
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i0 + i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < AG; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+          for (int j = 0; j < C::FN; ++j) asm volatile("" ::"v"(b[j]));
+        }
+      }
+    }
+  }
+  __syncthreads();  // the second product (or the next use of LDS) may restage the ring
+}
+
 __device__ inline uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ inline float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 // One kernel per operand layout (AKC, BKC): a run-time switch over the four main loops costs ~70
 // VGPRs and spills the 256x256 configuration.  The launcher groups products by layout.
-template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA, int DIAG = 0>
+template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA, int DIAG = 0, bool RING5 = false>
 __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(GemmGroup g) {
+  static_assert(!RING5 || (SPLIT == 1 && TB == 256 && !REGA), "the five-half-tile ring: plain bf16 on 256 x 256 tiles");
   using C = Cfg<TB>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const GemmProb &p = g.p[blockIdx.z];
@@ -353,7 +418,8 @@ __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(Gemm
     const long sA = prod ? p.sA2 : p.sA, sB = prod ? p.sB2 : p.sB;
     BfOperand A{Ah + b * sA, (const uint16_t *)(prod ? p.A2l : p.Al) + b * sA};
     BfOperand B{(const uint16_t *)(prod ? p.B2 : p.B) + b * sB, (const uint16_t *)(prod ? p.B2l : p.Bl) + b * sB};
-    mainloop<SPLIT, TB, AKC, BKC, REGA, DIAG>(acc, A, B, n, m0, n0, lds, wave, lane);
+    if constexpr (RING5) mainloop_ring5<TB, AKC, BKC, DIAG>(acc, A, B, n, m0, n0, lds, wave, lane);
+    else mainloop<SPLIT, TB, AKC, BKC, REGA, DIAG>(acc, A, B, n, m0, n0, lds, wave, lane);
   }
 
   const int wm = (wave / C::WN) * (C::FM * 16), wn = (wave % C::WN) * (C::FN * 16);
@@ -383,12 +449,12 @@ __global__ __launch_bounds__(Cfg<TB>::WAVES * 64) void gemm_pad_bf16_kernel(Gemm
     }
 }
 
-template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA = false, int DIAG = 0>
+template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA = false, int DIAG = 0, bool RING5 = false>
 int launch_one(const GemmGroup &g, hipStream_t s) {
   static bool attr_set = false;
-  const size_t lds = ring_bytes<SPLIT, TB>();
+  const size_t lds = RING5 ? (size_t)5 * 2 * TB * 2 * 32 : ring_bytes<SPLIT, TB>();
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA, DIAG>,
+    if (hipFuncSetAttribute((const void *)gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA, DIAG, RING5>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
@@ -396,7 +462,7 @@ int launch_one(const GemmGroup &g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = g.n / TB;
-  hipLaunchKernelGGL((gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA, DIAG>), dim3(tiles * tiles, g.batch, g.nprob),
+  hipLaunchKernelGGL((gemm_pad_bf16_kernel<SPLIT, TB, AKC, BKC, REGA, DIAG, RING5>), dim3(tiles * tiles, g.batch, g.nprob),
                      dim3(Cfg<TB>::WAVES * 64), lds, s, g);
   return check_launch();
 }
@@ -407,8 +473,23 @@ inline bool rega_on() {
   return on;
 }
 
+// CRW_GEMM_RING5=0: plain-bf16 256 x 256 products on the two-stage ring of 64-deep tiles (the round-2/3 loop) instead of the ring of
+// five 32-deep half-tiles
+inline bool ring5_on() {
+  static const bool on = [] { const char *e = getenv("CRW_GEMM_RING5"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int SPLIT, int TB>
 int launch_layout(const GemmGroup &g, int code, hipStream_t s) {
+  if constexpr (SPLIT == 1 && TB == 256) {
+    if (ring5_on() && !rega_on()) switch (code) {
+        case 3: return launch_one<SPLIT, TB, true, true, false, 0, true>(g, s);
+        case 2: return launch_one<SPLIT, TB, true, false, false, 0, true>(g, s);
+        case 1: return launch_one<SPLIT, TB, false, true, false, 0, true>(g, s);
+        default: return launch_one<SPLIT, TB, false, false, false, 0, true>(g, s);
+      }
+  }
   if constexpr (SPLIT == 1) {
     if (rega_on()) switch (code) {
         case 3: return launch_one<SPLIT, TB, true, true, true>(g, s);

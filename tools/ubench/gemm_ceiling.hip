@@ -20,16 +20,16 @@ thread_local int g_last_hip_error = 0;
 using namespace crw;
 
 static const char *MODE[] = {"shipped kernel", "MFMAs alone", "+ LDS fragment reads", "+ barrier per k-tile", "+ LDS-DMA stream (all)",
-                             "LDS-DMA stream alone", "LDS-DMA stream + barrier"};
+                             "LDS-DMA stream alone", "LDS-DMA stream + barrier", "shipped kernel (again, last)"};
 
-template <int SPLIT, int TB, bool AKC, bool BKC, int DIAG>
+template <int SPLIT, int TB, bool AKC, bool BKC, int DIAG, bool RING5 = false>
 static double time_one(const GemmGroup &g, int iters) {
-  for (int i = 0; i < 2; ++i) (void)launch_one<SPLIT, TB, AKC, BKC, false, DIAG>(g, nullptr);
+  for (int i = 0; i < 2; ++i) (void)launch_one<SPLIT, TB, AKC, BKC, false, DIAG, RING5>(g, nullptr);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   hipEventRecord(e0, nullptr);
-  for (int i = 0; i < iters; ++i) (void)launch_one<SPLIT, TB, AKC, BKC, false, DIAG>(g, nullptr);
+  for (int i = 0; i < iters; ++i) (void)launch_one<SPLIT, TB, AKC, BKC, false, DIAG, RING5>(g, nullptr);
   hipEventRecord(e1, nullptr);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -44,7 +44,8 @@ static void sweep(const GemmGroup &g, const char *layout) {
   const double flops = 2.0 * g.n * (double)g.n * g.n * g.batch * (SPLIT == 3 ? 3 : 1);
   const int bk = tile_bk<SPLIT, TB>();
   const double ktiles_per_cu = (double)(g.n / TB) * (g.n / TB) * g.batch * (g.n / bk) / 256.0;  // k-tiles a CU works through
-  double ms[7];
+  double ms[8];
+  (void)time_one<SPLIT, TB, AKC, BKC, 0>(g, 40);  // warm-up: the chip settles into the clock it holds under this kernel
   ms[0] = time_one<SPLIT, TB, AKC, BKC, 0>(g, 10);
   ms[1] = time_one<SPLIT, TB, AKC, BKC, 1>(g, 10);
   ms[2] = time_one<SPLIT, TB, AKC, BKC, 2>(g, 10);
@@ -52,17 +53,39 @@ static void sweep(const GemmGroup &g, const char *layout) {
   ms[4] = time_one<SPLIT, TB, AKC, BKC, 4>(g, 10);
   ms[5] = time_one<SPLIT, TB, AKC, BKC, 5>(g, 10);
   ms[6] = time_one<SPLIT, TB, AKC, BKC, 6>(g, 10);
+  ms[7] = time_one<SPLIT, TB, AKC, BKC, 0>(g, 10);
   const double stage_kb = (SPLIT == 3 ? 4 : 2) * TB * 2.0 * bk / 1024.0;
   printf("tile %3d x %3d, BK %2d, %s, %s  (%.0f KiB of operands per k-tile, %d workgroup(s) per CU)\n", TB, TB, bk,
          SPLIT == 3 ? "hi/lo pairs (3 MFMAs per product)" : "plain bf16", layout, stage_kb, TB == 128 && SPLIT == 1 ? 2 : 1);
-  for (int m = 0; m < 7; ++m) {
+  for (int m = 0; m < 8; ++m) {
     const double us_tile = ms[m] * 1e3 / ktiles_per_cu;
-    if (m <= 4)
+    if (m <= 4 || m == 7)
       printf("    %-28s %8.1f us/launch  %7.1f TFLOP/s executed = %.3f of 2500   %6.3f us per k-tile and CU\n", MODE[m], ms[m] * 1e3,
              flops / (ms[m] * 1e-3) / 1e12, flops / (ms[m] * 1e-3) / 1e12 / 2500.0, us_tile);
     else
       printf("    %-28s %8.1f us/launch  %7.1f GB/s per CU into LDS = %5.2f TB/s chip      %6.3f us per k-tile and CU\n", MODE[m],
              ms[m] * 1e3, stage_kb * 1024.0 / (us_tile * 1e-6) / 1e9, stage_kb * 1024.0 / (us_tile * 1e-6) / 1e12 * 256, us_tile);
+  }
+}
+
+// the ring of five 32-deep half-tiles (plain bf16, 256 x 256; gemm_bf16.hip mainloop_ring5): whole loop, without its DMA stream
+// (both buffers of a pair hold real tiles), and its DMA stream + barrier alone
+template <bool AKC, bool BKC>
+static void sweep_ring5(const GemmGroup &g, const char *layout) {
+  const double flops = 2.0 * g.n * (double)g.n * g.n * g.batch;
+  const double ktiles_per_cu = (double)(g.n / 256) * (g.n / 256) * g.batch * (g.n / 64) / 256.0;
+  (void)time_one<1, 256, AKC, BKC, 0, true>(g, 40);
+  const double ms[3] = {time_one<1, 256, AKC, BKC, 0, true>(g, 10), time_one<1, 256, AKC, BKC, 3, true>(g, 10), time_one<1, 256, AKC, BKC, 6, true>(g, 10)};
+  static const char *nm[3] = {"shipped kernel", "without the LDS-DMA stream", "LDS-DMA stream + barrier"};
+  printf("tile 256 x 256, ring of five 32-deep half-tiles (one barrier per 64 deep), plain bf16, %s  (64 KiB of operands per 64 deep, 1 workgroup per CU)\n", layout);
+  for (int m = 0; m < 3; ++m) {
+    const double us_tile = ms[m] * 1e3 / ktiles_per_cu;
+    if (m < 2)
+      printf("    %-28s %8.1f us/launch  %7.1f TFLOP/s executed = %.3f of 2500   %6.3f us per 64 deep and CU\n", nm[m], ms[m] * 1e3,
+             flops / (ms[m] * 1e-3) / 1e12, flops / (ms[m] * 1e-3) / 1e12 / 2500.0, us_tile);
+    else
+      printf("    %-28s %8.1f us/launch  %7.1f GB/s per CU into LDS = %5.2f TB/s chip      %6.3f us per 64 deep and CU\n", nm[m], ms[m] * 1e3,
+             65536.0 / (us_tile * 1e-6) / 1e9, 65536.0 / (us_tile * 1e-6) / 1e12 * 256, us_tile);
   }
 }
 
@@ -106,6 +129,9 @@ int main(int argc, char **argv) {
   // A k-contiguous, B r-contiguous (ta = 0, tb = 0)
   sweep<1, 256, true, true>(g, "A [m][k], B [n][k] (ds_read_b128 both)");
   sweep<1, 256, true, false>(g, "A [m][k], B [k][n] (B by ds_read_b64_tr_b16)");
+  sweep_ring5<true, true>(g, "A [m][k], B [n][k]");
+  sweep_ring5<true, false>(g, "A [m][k], B [k][n]");
+  sweep_ring5<false, false>(g, "A [k][m], B [k][n]");
   sweep<1, 128, true, true>(g, "A [m][k], B [n][k]");
   sweep<1, 128, true, false>(g, "A [m][k], B [k][n]");
   sweep<3, 256, true, true>(g, "A [m][k], B [n][k]");
