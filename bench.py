@@ -190,7 +190,7 @@ def resnet_event_kernels(ev, P, steps):
         mfma_frac = alg / (kms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]
         hbm_gbps = nbytes / (kms * 1e-3) / 1e9
         hbm_frac = hbm_gbps / HBM_PEAK_GBPS
-        e = {"kernel": name, "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // steps, "timed_launches": len(pairs),
+        e = {"kernel": name, "_key": key, "traffic": None, "launch_us": kms * 1e3, "launches_per_step": len(pairs) // steps, "timed_launches": len(pairs),
              "algorithmic_flops_per_launch": alg, "algorithmic_bytes_per_launch": nbytes,
              "mfma_frac": mfma_frac, "mfma_tflops": alg / (kms * 1e-3) / 1e12,
              "mfma_executed_tflops": alg * 3 * ex / (kms * 1e-3) / 1e12,
@@ -205,24 +205,39 @@ def resnet_event_kernels(ev, P, steps):
             e.update({"bound": "mfma", "achieved": alg / (kms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": mfma_frac})
         out.append(e)
     out.sort(key=lambda k_: -k_["launch_us"] * k_["launches_per_step"])
-    # HBM traffic of layer1's weight gradient (the dominant matrix-core kernel of the step) from the committed in-step PMC passes
-    # (profiles/r03_pmc_resnet.json: rn_wgrad_kernel<64, 64, 32> is launched exactly twice per step, for layer1's two convolutions),
-    # attached only while the kernel still takes the time recorded with the counters (+ its slab sum inside the event bracket)
+    # HBM traffic per launch from the committed in-step PMC passes over this same command (rocprofv3 cannot run inside bench):
+    # profiles/r04_pmc_resnet.json, "by_grid" = per (kernel instance, grid size) -- the grid tells the layers of one instance apart
+    # (gathered product: blocks = patch tiles x column tiles x groups, 512 threads each).  Constants are attached only while the
+    # kernel still takes the time recorded with them (within 10 %).
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_resnet.json")))["kernels"]
-        rec = pmc["crw::rn_wgrad_kernel<64, 64, 32>"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_resnet.json")))["by_grid"]
+        Ppad = (P + 127) // 128 * 128
         for k in out:
-            if k["kernel"].startswith("rn_wgrad_kernel 5x5x64 -> 5x5x64") and P == 16128:
-                per_launch_us = rec["us_per_step"] / rec["launches_per_step"]
-                if abs(k["launch_us"] - per_launch_us - 10.0) <= 0.08 * per_launch_us:
-                    k["traffic"] = (rec["hbm_read_MB"] + rec["hbm_write_MB"]) * 1e6 / rec["launches_per_step"]
-                    k["traffic_note"] = ("HBM bytes per launch inside the step (profiles/r03_pmc_resnet.json: 2*1024*FETCH_SIZE + 1024*WRITE_SIZE, "
-                                         "separate passes); algorithmic: both operands' planes once = 2 * P * 25 * 64 * 4 B = 206 MB")
-                else:
-                    k["traffic_note"] = (f"committed PMC constants NOT attached: live {k['launch_us']:.1f} us vs {per_launch_us:.1f} us "
-                                         "(+ ~10 us slab sum) recorded with them")
+            key = k.get("_key")
+            if not key or key[0] != "rn_conv" or key[1] not in (crw_hip.RN_FWD, crw_hip.RN_BWD):
+                continue
+            _, _, Hs, Ws, Cs, Hd, Wd, N, kk, stride, pad = key
+            tn = 128 if N % 128 == 0 else 64
+            grid = str((Ppad // 128) * (N // tn) * Hd * Wd * 512)
+            cands = [(abs(v[grid]["us_per_launch"] - k["launch_us"]), name, v[grid]) for name, v in pmc.items()
+                     if name.startswith(f"crw::rn_conv_spec_kernel<{tn},") and grid in v]
+            if not cands:
+                continue
+            d, name, rec = min(cands)
+            if d <= 0.10 * rec["us_per_launch"]:
+                k["traffic"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+                k["traffic_note"] = (f"HBM bytes per launch inside the step, committed PMC passes profiles/r04_pmc_resnet.json ({name}, grid {grid}: "
+                                     f"reads 2*1024*FETCH_SIZE = {rec['hbm_read_bytes_per_launch'] / 1e6:.1f} MB (gfx950 correction), writes "
+                                     f"1024*WRITE_SIZE = {rec['hbm_write_bytes_per_launch'] / 1e6:.1f} MB, separate passes); algorithmic: "
+                                     f"{k['algorithmic_bytes_per_launch'] / 1e6:.1f} MB (source planes + fp32 destination once; the fused epilogues "
+                                     "of the backward-data products read the consuming layer's mask and Z planes on top of that)")
+            else:
+                k["traffic_note"] = (f"committed PMC constants NOT attached: live {k['launch_us']:.1f} us vs {rec['us_per_launch']:.1f} us recorded "
+                                     f"with them ({name}, grid {grid})")
     except Exception:
         pass
+    for k in out:
+        k.pop("_key", None)
     return out
 
 
