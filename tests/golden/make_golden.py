@@ -373,13 +373,18 @@ def run_resnet_train_case(ref_model, ref_encoder, name, B, T, N, tau, seed, hw=(
     seq = torch.stack([unfold_items(rg, T, h, w, oh, 0, i * T) for i in range(B)])
     crw = ref_model.CRW(enc, tau, False)
     feats = {}
-    hook = enc.register_forward_hook(lambda m, i, o: feats.__setitem__("emb", o.detach().clone()))
+
+    def keep(m, i, o):  # the encoder's output and (below) the gradient that reaches it
+        feats["emb"] = o.detach().clone()
+        o.register_hook(lambda gr: feats.__setitem__("demb", gr.detach().clone()))
+
+    hook = enc.register_forward_hook(keep)
     with cuda_is_cpu():
         loss, A = crw(seq)
     hook.remove()
     loss.backward()
     out = dict(seq=seq.numpy(), tau=np.float32(tau), seed=np.int32(seed), emb=feats["emb"].numpy(), A=A.detach().numpy(),
-               loss=loss.detach().numpy())
+               loss=loss.detach().numpy(), demb=feats["demb"].numpy())
     keep = ("fc0.weight", "bn0.weight", "model.conv1.weight", "model.layer1.0.conv1.weight", "model.layer2.0.downsample.0.weight",
             "model.layer4.0.bn2.bias", "model.fc.weight", "model.fc.bias")
     names, norms = [], []
@@ -472,8 +477,8 @@ def main():
     run_resnet_train_case(ref_model, ref_encoder, "resnet_train_B2T4N5", 2, 4, 5, 0.05, 11)
     # the reference's cfg5-shaped encoder input: 32 x 32 patches, overlap (24, 0) (scripts/test/test_mc1.py:19,21) -- layer4's map is
     # 2 x 2 there, so the global average pool is no longer the identity; and a non-square size whose stem rows need two column tiles
-    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_32x32_B2T3N4", 2, 3, 4, 0.05, 12, hw=(32, 32), oh=24, eval_after=True)
-    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_20x27_B1T3N5", 1, 3, 5, 0.05, 13, hw=(20, 27), oh=10)
+    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_32x32_B2T4N5", 2, 4, 5, 0.05, 12, hw=(32, 32), oh=24, eval_after=True)
+    run_resnet_train_case(ref_model, ref_encoder, "resnet_train_20x27_B2T4N5", 2, 4, 5, 0.05, 13, hw=(20, 27), oh=10)
     # whole-radargram pipeline through the reference's own driver (scripts/test/test_all.py main)
     lpc = dict(CXT_SIZE=4, RADIUS=4, TEMP=0.1, KNN=5)
     run_segment_case(ref_dataset, "segment_ds0_reverse", 0, 4, 8, (8, 8), 4, 52, 3, 2, lpc, True, False, None, 51)

@@ -339,7 +339,7 @@ def test_correction_step_error_policy(status, raises):
     run_segment_golden(g, broken, "cpu")
 
 
-RESNET_TRAIN_CASES = ["resnet_train_B2T4N5", "resnet_train_32x32_B2T3N4", "resnet_train_20x27_B1T3N5"]
+RESNET_TRAIN_CASES = ["resnet_train_B2T4N5", "resnet_train_32x32_B2T4N5", "resnet_train_20x27_B2T4N5"]
 
 
 @pytest.mark.parametrize("name", RESNET_TRAIN_CASES)

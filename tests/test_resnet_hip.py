@@ -593,7 +593,7 @@ def test_resnet_native_pass_is_reproducible(hip):
                 assert torch.equal(a, b), f"tensor {k} differs between two runs of the same step"
 
 
-@pytest.mark.parametrize("name", ["resnet_train_B2T4N5", "resnet_train_32x32_B2T3N4", "resnet_train_20x27_B1T3N5"])
+@pytest.mark.parametrize("name", ["resnet_train_B2T4N5", "resnet_train_32x32_B2T4N5", "resnet_train_20x27_B2T4N5"])
 def test_resnet_hip_training_step_matches_reference(hip, monkeypatch, name):
     """SURVEY section 8 row a8 on the hand-written kernels: CRW.forward + backward with the reference's DEFAULT encoder against
     the reference's own CPU run (fixtures resnet_train_*: 16x16 patches; 32x32 with overlap 24, scripts/test/test_mc1.py:19,21;
@@ -620,23 +620,37 @@ def test_resnet_hip_training_step_matches_reference(hip, monkeypatch, name):
     np.testing.assert_allclose(enc.model.bn1.running_mean.cpu().numpy(), g["model.bn1.running_mean"], rtol=1e-3, atol=1e-5)
     names = [k for k, _ in enc.named_parameters()]
     assert names == list(g["grad_names"])
-    # A FREE-RUNNING comparison (the reference's fp32 run picks its own max-pool arg-max pixels / ReLU gates): with the 15-40 patches
-    # of these fixtures one routing flip moves the gradients BELOW the pool -- sums over everything, three entries each for the
-    # stem's parameters -- by a few per cent: 5 % there, 2 % above the pool.  Entry-by-entry equality is what
-    # test_resnet_hip_matches_pytorch_modules holds against the teacher-forced reference at the same patch sizes.
+    # Gradients, two ways.  (1) End to end -- HIP walk + HIP encoder against the reference's fp32 run: every gradient's norm.
+    # (2) The encoder alone: the reference's OWN dLoss/dEmb (fixture `demb`) pushed through the HIP backward, entry by entry above the
+    # max-pool; below it -- and for (1) -- a FREE-RUNNING comparison is limited by routing decisions (the reference's fp32 forward
+    # picks its own arg-max pixels / ReLU gates; with the 40 patches of these fixtures one flip moves the sums below the pool by a
+    # few per cent): direction + norm there.  Entry-by-entry equality below the pool is what test_resnet_hip_matches_pytorch_modules
+    # holds against the teacher-forced reference at the same patch sizes.
     below_pool = ("fc0.weight", "bn0.weight", "bn0.bias", "model.conv1.weight", "model.bn1.weight", "model.bn1.bias")
     for (k, p_), ref_norm in zip(enc.named_parameters(), g["grad_norms"]):
         tol = 5e-2 if k in below_pool else 2e-2
         got = float(p_.grad.double().norm())
         assert abs(got - ref_norm) <= tol * ref_norm + 1e-4, (k, got, ref_norm)
-        if "grad." + k in g:
-            ref = g["grad." + k]
-            if k in below_pool:  # single entries move with single routing decisions: direction and (above) norm
-                a_, b_ = p_.grad.double().flatten().cpu(), torch.as_tensor(ref).double().flatten()
-                cos = float(torch.dot(a_, b_) / (a_.norm() * b_.norm() + 1e-30))
-                assert cos > 0.995, (k, cos)
-            else:
-                np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=tol, atol=(tol / 10) * np.abs(ref).max(), err_msg=k)
+    torch.manual_seed(int(g["seed"]))
+    enc2 = crw_encoder.Resnet(False).cuda().train(True)
+    seq_d = torch.as_tensor(g["seq"]).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _no_library_convs(monkeypatch)
+        emb2 = enc2(seq_d.reshape(-1, 1, *seq_d.shape[-2:]))
+        emb2.backward(torch.as_tensor(g["demb"]).cuda())
+    monkeypatch.undo()
+    np.testing.assert_allclose(emb2.detach().cpu().numpy(), g["emb"], rtol=1e-3, atol=1e-4 * np.abs(g["emb"]).max())
+    for k, p_ in enc2.named_parameters():
+        if "grad." + k not in g:
+            continue
+        ref = g["grad." + k]
+        a_, b_ = p_.grad.double().flatten().cpu(), torch.as_tensor(ref).double().flatten()
+        cos = float(torch.dot(a_, b_) / (a_.norm() * b_.norm() + 1e-30))
+        if k in below_pool:
+            assert cos > 0.995 and abs(float(a_.norm() / b_.norm()) - 1) < 5e-2, (k, cos, float(a_.norm() / b_.norm()))
+        else:
+            np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max(), err_msg=k)
     if "emb_eval" in g:
         for k, b in enc.named_buffers():
             if b.is_floating_point():

@@ -14,7 +14,7 @@ for p in (ROOT, os.path.join(ROOT, "radar-sounder-crw_amd")):
 import encoder as crw_encoder  # noqa: E402
 from oracle import crw_oracle as orc  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "resnet_train_32x32_B2T3N4"
+name = sys.argv[1] if len(sys.argv) > 1 else "resnet_train_32x32_B2T4N5"
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
 torch.manual_seed(int(g["seed"]))
 base = crw_encoder.Resnet(False).cuda()
