@@ -473,10 +473,14 @@ inline bool rega_on() {
   return on;
 }
 
-// CRW_GEMM_RING5=0: plain-bf16 256 x 256 products on the two-stage ring of 64-deep tiles (the round-2/3 loop) instead of the ring of
-// five 32-deep half-tiles
+// CRW_GEMM_RING5=1 (opt-in): plain-bf16 256 x 256 products on the ring of five 32-deep half-tiles instead of the two-stage ring of
+// 64-deep tiles.  Measured both ways (profiles/r04_gemm_ceiling.log, profiles/r04_gemm_ring5.log): back to back in the stand-alone
+// micro-benchmark the five-slot ring is 6 % faster (1151 against 1080 TFLOP/s), through the library from the walk it is 4-9 %
+// SLOWER in all four operand layouts and the whole N = 4096 walk takes 48.0 against 46.3 ms -- and the micro-benchmark's
+// "LDS-DMA stream + barrier" variant runs at the same 38-44 GB/s per CU with either ring: deeper prefetch does not raise what a
+// barrier-synchronised workgroup takes in, so the two-stage ring stays the default.
 inline bool ring5_on() {
-  static const bool on = [] { const char *e = getenv("CRW_GEMM_RING5"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char *e = getenv("CRW_GEMM_RING5"); return e && e[0] == '1'; }();
   return on;
 }
 

@@ -22,6 +22,7 @@ seq = torch.as_tensor(g["seq"]).cuda()
 B, T, N, h, w = seq.shape
 x = seq.reshape(-1, 1, h, w)
 out = {}
+stats = {}
 for tag, conv, dt in (("hip", "bf16x3", torch.float32), ("torch32", None, torch.float32), ("torch64", None, torch.float64)):
     m = copy.deepcopy(base).to(dt)
     m.hip_convs = conv
@@ -30,6 +31,7 @@ for tag, conv, dt in (("hip", "bf16x3", torch.float32), ("torch32", None, torch.
     loss, _ = orc.walk_loss_torch(emb.double() if dt == torch.float64 else emb, float(g["tau"]))
     loss.backward()
     out[tag] = {k: p.grad.double().flatten().cpu() for k, p in m.named_parameters()}
+    stats[tag] = {k: b.double().cpu() for k, b in m.named_buffers() if b.is_floating_point()}
     print(tag, "loss", loss.item(), "fixture", float(g["loss"]))
 out["fixture"] = {k[5:]: torch.as_tensor(v).double().flatten() for k, v in g.items() if k.startswith("grad.")}
 tags = list(out)
@@ -40,3 +42,17 @@ for k in out["fixture"]:
             u, v = out[a][k], out[b][k]
             print(f"   {a:8s} vs {b:8s}: |u-v|/|v| = {float((u - v).norm() / v.norm()):.3e}   cos = {float(torch.dot(u, v) / (u.norm() * v.norm())):.7f}"
                   f"   max|u-v|/max|v| = {float((u - v).abs().max() / v.abs().max()):.3e}")
+
+print("BatchNorm running statistics after the step, worst relative difference per buffer (vs torch64) and the channel's mean^2 / var there")
+for k in stats["torch64"]:
+    if not k.endswith("running_var"):
+        continue
+    ref = stats["torch64"][k]
+    mean = stats["torch64"][k.replace("running_var", "running_mean")] / 0.1   # one momentum step from 0
+    var = (ref - 0.9) / 0.1                                                    # one momentum step from 1 (unbiased batch variance)
+    line = f"   {k:44s}"
+    for tag in ("hip", "torch32"):
+        d = ((stats[tag][k] - ref).abs() / 0.1 / var.abs().clamp_min(1e-30))
+        i = int(d.argmax())
+        line += f"  {tag}: {float(d.max()):.2e} (mean^2/var {float(mean[i] ** 2 / var[i]):.1e}, var {float(var[i]):.2e})"
+    print(line)
