@@ -110,6 +110,11 @@ int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, c
  * (the reference fills them with masked keys whose softmax weight is exactly 0). */
 int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp,
                        int knn, int first_frame, float *W, int32_t *I, crw_stream_t stream);
+/* The same on a 2-D node grid: the N nodes of a frame are an (N / grid_w) x grid_w grid in row-major order and the band is the
+ * Euclidean disc (i - i')^2 + (j - j')^2 < radius^2 of MaskedAttention (src/imported/maskedatt.py:222-245); grid_w = 1 is
+ * crw_labelprop_topk (a radargram's frames are N x 1 columns of patches, the only grid the reference's scripts produce). */
+int crw_labelprop_topk_grid(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp, int knn, int first_frame,
+                            int grid_w, float *W, int32_t *I, crw_stream_t stream);
 
 /* seed [N] float class ids of frame 0 (NULL: rows of L for frames < first_frame are already
  * filled by the caller); W,I from crw_labelprop_topk with the same first_frame;

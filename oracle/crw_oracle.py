@@ -226,11 +226,13 @@ def walk_loss_torch(emb, tau, At_out=None):
 MASK_NEG = -1e10
 
 
-def band_bias(N, radius, dtype=np.float32):
-    """bias[m,q] = 0 if |m-q| < radius else -1e10 (patch grid is N x 1, so the Euclidean radius
-    mask of MaskedAttention degenerates to a band)."""
-    i = np.arange(N)
-    return np.where(np.abs(i[:, None] - i[None, :]).astype(np.float64) < radius, 0.0, MASK_NEG).astype(dtype)
+def band_bias(N, radius, dtype=np.float32, grid_w=1):
+    """bias[m,q] = 0 if the nodes m and q are closer than `radius` else -1e10.  The N nodes form an (N / grid_w) x grid_w grid in
+    row-major order and the distance is Euclidean (MaskedAttention.make, src/imported/maskedatt.py:232-245); a radargram's patch
+    grid is N x 1 (grid_w = 1), where the mask degenerates to the band |m-q| < radius."""
+    i, j = np.arange(N) // grid_w, np.arange(N) % grid_w
+    d = np.sqrt(((i[:, None] - i[None, :]) ** 2 + (j[:, None] - j[None, :]) ** 2).astype(np.float32))
+    return np.where(d < radius, 0.0, MASK_NEG).astype(dtype)
 
 
 def seed_labels(seg_ref, N):
@@ -242,13 +244,13 @@ def seed_labels(seg_ref, N):
     return seg_ref[idx, 0].astype(np.float32)
 
 
-def labelprop_weights(ehat, n, cxt_size, radius, temp, knn, dtype=np.float32):
+def labelprop_weights(ehat, n, cxt_size, radius, temp, knn, dtype=np.float32, grid_w=1):
     """Top-k neighbour weights/indices of frame n against frames 0..n-1.
     Returns (W [knn,N], I [knn,N]) with I addressing the (possibly truncated) key list."""
     T, N, C = ehat.shape
     keys = ehat[:n].reshape(n * N, C).astype(dtype)
     q = ehat[n].astype(dtype)
-    S = (keys @ q.T).reshape(n, N, N) + band_bias(N, radius, dtype)[None]
+    S = (keys @ q.T).reshape(n, N, N) + band_bias(N, radius, dtype, grid_w)[None]
     S = S.reshape(n * N, N) / dtype(temp)
     if S.shape[0] > (cxt_size + 1) * N:
         S = np.concatenate([S[:N], S[-N * cxt_size:]], 0)
@@ -260,10 +262,10 @@ def labelprop_weights(ehat, n, cxt_size, radius, temp, knn, dtype=np.float32):
     return W.astype(dtype), I
 
 
-def labelprop(emb, seed, nclasses, cxt_size, radius, temp, knn, dtype=np.float32):
+def labelprop(emb, seed, nclasses, cxt_size, radius, temp, knn, dtype=np.float32, grid_w=1):
     """emb [T,N,C] raw features (already flipped by the caller if use_last), seed [N] float labels
     of frame 0 -> pred [N,T] float labels.  Indices returned for the truncated key list are used
-    against the *untruncated* label list (quirk Q7)."""
+    against the *untruncated* label list (quirk Q7).  grid_w: see band_bias."""
     T, N, C = emb.shape
     ehat = l2_normalize(emb, dtype).astype(dtype)
     L = np.zeros((T * N, nclasses), dtype)
@@ -271,7 +273,7 @@ def labelprop(emb, seed, nclasses, cxt_size, radius, temp, knn, dtype=np.float32
     pred = np.zeros((N, T), np.float32)
     pred[:, 0] = seed
     for n in range(1, T):
-        W, I = labelprop_weights(ehat, n, cxt_size, radius, temp, knn, dtype)
+        W, I = labelprop_weights(ehat, n, cxt_size, radius, temp, knn, dtype, grid_w)
         p = (L[I] * W[..., None]).sum(0)  # [N, M]
         L[n * N:(n + 1) * N] = p
         pred[:, n] = p.argmax(-1)

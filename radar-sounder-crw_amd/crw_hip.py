@@ -47,6 +47,7 @@ SIGNATURES = {
     "crw_affinity_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_f, _p, _p, _p]),
     "crw_normalize": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_topk": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _p, _p, _p]),
+    "crw_labelprop_topk_grid": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
     "crw_linear128_wgrad_ws_bytes": (_c_sz, [_c_int]),
@@ -257,13 +258,14 @@ def normalize(emb):
     return ehat
 
 
-def labelprop_topk(ehat, cxt_size, radius, temp, knn, first_frame=1):
+def labelprop_topk(ehat, cxt_size, radius, temp, knn, first_frame=1, grid_w=1):
+    """grid_w: the N nodes of a frame form an (N / grid_w) x grid_w grid (1 = a radargram's column of patches)"""
     T, N, C = ehat.shape
     W = torch.empty(T - first_frame, knn, N, device=ehat.device, dtype=torch.float32)
     I = torch.empty(T - first_frame, knn, N, device=ehat.device, dtype=torch.int32)
-    _check(lib().crw_labelprop_topk(_dev(ehat, "ehat"), T, N, C, int(cxt_size), int(radius), float(temp), int(knn),
-                                    int(first_frame), _dev(W, "W"), _dev(I, "I", torch.int32), _stream()),
-           "crw_labelprop_topk")
+    _check(lib().crw_labelprop_topk_grid(_dev(ehat, "ehat"), T, N, C, int(cxt_size), int(radius), float(temp), int(knn),
+                                         int(first_frame), int(grid_w), _dev(W, "W"), _dev(I, "I", torch.int32), _stream()),
+           "crw_labelprop_topk_grid")
     return W, I
 
 

@@ -19,17 +19,24 @@ namespace {
 
 constexpr int MAX_KNN = 64;
 
+// Nodes of a frame form a gh x gw grid (node = i * gw + j; a radargram's patch column: gw = 1).  A key (i', j') is in band for the
+// query (i, j) when (i - i')^2 + (j - j')^2 < radius^2 (MaskedAttention.make, src/imported/maskedatt.py:232-245); candidates are the
+// keys of the clipped bounding box of that disc, in node order, and box keys outside the disc never score (the reference gives them
+// logit -1e10 / temp: softmax weight exactly 0).
 __global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__restrict__ ehat, int T, int N, int C,
                                                              int cxt, int radius, float temp, int knn,
-                                                             int first_frame, float *__restrict__ W,
+                                                             int first_frame, int gw, float *__restrict__ W,
                                                              int32_t *__restrict__ I) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int q = blockIdx.x, n = blockIdx.y + first_frame;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool trunc = n > cxt + 1;
   const int nf = trunc ? cxt + 1 : n;
-  const int lo = max(0, q - radius + 1), hi = min(N - 1, q + radius - 1);
-  const int bw = hi - lo + 1;
+  const int gh = N / gw, qi = q / gw, qj = q - qi * gw;
+  const int lo = max(0, qi - radius + 1), hi = min(gh - 1, qi + radius - 1);        // box rows
+  const int lj = max(0, qj - radius + 1), hj = min(gw - 1, qj + radius - 1);        // box columns
+  const int bwj = hj - lj + 1;
+  const int bw = (hi - lo + 1) * bwj;                                               // keys of the box per context frame
   const int ncand = nf * bw;
 
   float *qv = smem;                       // [C] (padded to a multiple of 4)
@@ -45,7 +52,9 @@ __global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__rest
   // 16 lanes per candidate
   const int sub = tid & 15, grp = tid >> 4;  // 16 groups per block
   for (int cand = grp; cand < ncand; cand += 16) {
-    const int p = cand / bw, m = lo + cand % bw;
+    const int p = cand / bw, r = cand - p * bw;
+    const int mi = lo + r / bwj, mj = lj + r % bwj, m = mi * gw + mj;
+    const bool inside = (mi - qi) * (mi - qi) + (mj - qj) * (mj - qj) < radius * radius;  // (always, on an N x 1 grid)
     const int frame = trunc ? (p == 0 ? 0 : n - cxt + (p - 1)) : p;
     const float *key = ehat + ((long)frame * N + m) * C;
     float d = 0.f;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__rest
     d += __shfl_xor(d, 4);
     d += __shfl_xor(d, 2);
     d += __shfl_xor(d, 1);
-    if (sub == 0) val[cand] = d / temp;
+    if (sub == 0) val[cand] = inside ? d / temp : -INFINITY;
   }
   __syncthreads();
 
@@ -101,8 +110,8 @@ __global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__rest
     int idx = 0;
     if (v != -INFINITY) {
       w = expf(v - vmax) / ssum;
-      const int c = sel_i[tid];
-      idx = (c / bw) * N + lo + c % bw;
+      const int c = sel_i[tid], r = c % bw;
+      idx = (c / bw) * N + (lo + r / bwj) * gw + lj + r % bwj;
     }
     const long o = ((long)(n - first_frame) * knn + tid) * N + q;
     W[o] = w;
@@ -293,19 +302,25 @@ using namespace crw;
 
 extern "C" {
 
-int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp, int knn,
-                       int first_frame, float *W, int32_t *I, crw_stream_t stream) {
+int crw_labelprop_topk_grid(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp, int knn, int first_frame,
+                            int grid_w, float *W, int32_t *I, crw_stream_t stream) {
   crw::clear_stale_error();
   if (!ehat || !W || !I || T < 2 || N < 1 || C < 1 || cxt_size < 1 || radius < 1 || knn < 1 || knn > MAX_KNN ||
-      !(temp > 0.f) || first_frame < 1 || first_frame >= T)
+      !(temp > 0.f) || first_frame < 1 || first_frame >= T || grid_w < 1 || N % grid_w)
     return CRW_EINVAL;
+  const long gh = N / grid_w;
   const long max_nf = (long)(cxt_size + 1 < T - 1 ? cxt_size + 1 : T - 1);
-  const long max_bw = (2L * radius - 1 < N) ? 2L * radius - 1 : N;
-  const size_t lds = (((size_t)C + 3) & ~(size_t)3) * 4 + (size_t)(max_nf * max_bw) * 4;
+  const long max_bi = (2L * radius - 1 < gh) ? 2L * radius - 1 : gh, max_bj = (2L * radius - 1 < grid_w) ? 2L * radius - 1 : grid_w;
+  const size_t lds = (((size_t)C + 3) & ~(size_t)3) * 4 + (size_t)(max_nf * max_bi * max_bj) * 4;
   if (lds > 60 * 1024) return CRW_EINVAL;
   hipLaunchKernelGGL(labelprop_topk_kernel, dim3(N, T - first_frame), dim3(256), lds, (hipStream_t)stream, ehat, T,
-                     N, C, cxt_size, radius, temp, knn, first_frame, W, I);
+                     N, C, cxt_size, radius, temp, knn, first_frame, grid_w, W, I);
   return check_launch();
+}
+
+int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp, int knn,
+                       int first_frame, float *W, int32_t *I, crw_stream_t stream) {
+  return crw_labelprop_topk_grid(ehat, T, N, C, cxt_size, radius, temp, knn, first_frame, 1, W, I, stream);
 }
 
 int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn,

@@ -46,34 +46,33 @@ class LabelPropVOS_CRW(object):
         return self.mask
 
     def _check_grid(self, h, w):
-        if w != 1:
-            raise NotImplementedError("radargram patch grids are N x 1 (one column of patches per frame); "
-                                      f"got a {h} x {w} grid")
-        if self.topk > h:
-            raise RuntimeError(f"KNN={self.topk} exceeds the number of nodes per frame ({h}); "
+        if self.topk > h * w:
+            raise RuntimeError(f"KNN={self.topk} exceeds the number of nodes per frame ({h * w}); "
                                "torch.topk in the reference raises for the first frame as well")
 
     def predict(self, feats, masks, curr_feat, ref_index=None, t=None):
-        """feats: list of n [1,C,N,1] context features; masks: list of n [1,M,N,1] soft labels;
-        curr_feat [1,C,N,1]  ->  soft labels of the current frame [1,M,N,1]."""
+        """feats: list of n [1,C,h,w] context features; masks: list of n [1,M,h,w] soft labels;
+        curr_feat [1,C,h,w]  ->  soft labels of the current frame [1,M,h,w].  A radargram's frames are columns of patches
+        (w = 1, what `utils.propagate` passes); any h x w grid is taken like the reference's (nodes in row-major order, the band
+        the Euclidean disc of `MaskedAttention`, src/imported/maskedatt.py:222-245)."""
         h, w = curr_feat.shape[-2:]
         self._check_grid(h, w)
         self._band(h, w, curr_feat.device)
-        n, N = len(feats), h
-        E = torch.cat(list(feats) + [curr_feat], 0)[..., 0].permute(0, 2, 1).contiguous().float()  # [n+1, N, C]
+        n, N = len(feats), h * w
+        E = torch.cat(list(feats) + [curr_feat], 0).flatten(2).permute(0, 2, 1).contiguous().float()  # [n+1, N, C]
         M = masks[0].shape[1]
         L = torch.empty((n + 1) * N, M, device=E.device, dtype=torch.float32)
-        L[:n * N] = torch.cat(list(masks), 0)[..., 0].permute(0, 2, 1).reshape(n * N, M)
-        Wt, It = crw_hip.labelprop_topk(E, self.cxt_size, self.radius, self.temperature, self.topk, first_frame=n)
+        L[:n * N] = torch.cat(list(masks), 0).flatten(2).permute(0, 2, 1).reshape(n * N, M)
+        Wt, It = crw_hip.labelprop_topk(E, self.cxt_size, self.radius, self.temperature, self.topk, first_frame=n, grid_w=w)
         crw_hip.labelprop_gather(None, Wt, It, n + 1, N, M, first_frame=n, L=L)
-        return L[n * N:].reshape(N, M).t().reshape(1, M, N, 1)
+        return L[n * N:].reshape(N, M).t().reshape(1, M, h, w)
 
-    def propagate_all(self, feats, seed, nclasses):
+    def propagate_all(self, feats, seed, nclasses, grid_w=1):
         """feats [T,N,C] (normalised features), seed [N] float class ids of frame 0
-        -> (pred [N,T] float class ids, L [T*N, M] soft labels)."""
+        -> (pred [N,T] float class ids, L [T*N, M] soft labels).  grid_w: the N nodes are an (N / grid_w) x grid_w grid."""
         T, N, C = feats.shape
-        self._check_grid(N, 1)
-        self._band(N, 1, feats.device)
-        Wt, It = crw_hip.labelprop_topk(feats, self.cxt_size, self.radius, self.temperature, self.topk, first_frame=1)
+        self._check_grid(N // grid_w, grid_w)
+        self._band(N // grid_w, grid_w, feats.device)
+        Wt, It = crw_hip.labelprop_topk(feats, self.cxt_size, self.radius, self.temperature, self.topk, first_frame=1, grid_w=grid_w)
         L, pred = crw_hip.labelprop_gather(seed.float().contiguous(), Wt, It, T, N, nclasses, first_frame=1)
         return pred, L

@@ -273,6 +273,33 @@ def run_labelprop_case(ref_utils, ref_lp, name, T, N, C, M, cfg, use_last, seed,
           f"label changes along-track={moved} change_idx={change_idx}")
 
 
+def run_labelprop_grid_case(ref_lp, name, T, h, w, C, M, cfg, seed, noise=0.35):
+    """The reference's LabelPropVOS_CRW.predict on a 2-D node grid (h x w nodes per frame, src/imported/labelprop.py:67-115 with the
+    Euclidean-radius mask of MaskedAttention, maskedatt.py:222-245), driven frame by frame the way src/utils.py:148-160 drives it
+    on its N x 1 grids.  Nodes are stored in row-major order: emb [T, h*w, C], seed [h*w], pred [h*w, T]."""
+    gen = torch.Generator().manual_seed(seed)
+    emb = moving_layer_features(T, h * w, C, noise, gen)                     # [T, N, C]
+    ehat = emb / emb.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    seed_lab = (torch.arange(h * w) // w * M // h).float()                    # M horizontal bands
+    lp = ref_lp.LabelPropVOS_CRW(cfg)
+    as_feat = lambda n: ehat[n].t().reshape(1, C, h, w)
+    mask = (seed_lab[None, :] == torch.arange(M)[:, None]).float().reshape(1, M, h, w)
+    feats, masks = [as_feat(0)], [mask]
+    pred = torch.zeros(h * w, T)
+    pred[:, 0] = seed_lab
+    with cuda_is_cpu():
+        for n in range(1, T):
+            mask = lp.predict(feats, masks, as_feat(n))
+            feats.append(as_feat(n))
+            masks.append(mask)
+            pred[:, n] = mask.argmax(1).flatten().float()
+    np.savez(os.path.join(HERE, name + ".npz"), emb=emb.numpy(), seed_labels=seed_lab.numpy(), grid=np.int32([h, w]),
+             nclasses=np.int32(M), cxt_size=np.int32(cfg["CXT_SIZE"]), radius=np.int32(cfg["RADIUS"]),
+             temp=np.float32(cfg["TEMP"]), knn=np.int32(cfg["KNN"]), pred=pred.numpy())
+    print(f"{name}: grid {h}x{w} pred{tuple(pred.shape)} classes={sorted(set(pred.flatten().tolist()))} "
+          f"label changes along the frames={int((pred[:, 1:] != pred[:, :-1]).sum())}")
+
+
 def layered_segmentation(rows, cols, M, gen, wiggle=3.0):
     """[rows, cols] class ids: M sub-horizontal bands whose interfaces undulate along-track."""
     c = torch.arange(cols).float()
@@ -473,6 +500,9 @@ def main():
                        dict(CXT_SIZE=8, RADIUS=6, TEMP=0.05, KNN=10), True, 33)
     run_labelprop_case(ref_utils, ref_lp, "labelprop_mc1_T100N12", 100, 12, 32, 4,
                        dict(CXT_SIZE=80, RADIUS=10, TEMP=0.01, KNN=10), False, 34)
+    # 2-D node grids (never produced by a radargram -- the reference's frames are N x 1 -- but accepted by its predict())
+    run_labelprop_grid_case(ref_lp, "labelprop_grid_T10_6x5", 10, 6, 5, 32, 3, dict(CXT_SIZE=3, RADIUS=2, TEMP=0.1, KNN=5), 35)
+    run_labelprop_grid_case(ref_lp, "labelprop_grid_T8_4x9", 8, 4, 9, 16, 4, dict(CXT_SIZE=20, RADIUS=3, TEMP=0.05, KNN=7), 36)
     run_resnet_case(ref_encoder, "resnet_seed11", 11)
     run_resnet_train_case(ref_model, ref_encoder, "resnet_train_B2T4N5", 2, 4, 5, 0.05, 11)
     # the reference's cfg5-shaped encoder input: 32 x 32 patches, overlap (24, 0) (scripts/test/test_mc1.py:19,21) -- layer4's map is

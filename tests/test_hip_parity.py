@@ -812,6 +812,43 @@ def test_predict_frame_by_frame_equals_batched(hip):
     assert lp.mask.shape == (1, N, N) and lp.mask_hw == (N, 1)
 
 
+@pytest.mark.parametrize("name", ["labelprop_grid_T10_6x5", "labelprop_grid_T8_4x9"])
+def test_labelprop_on_2d_grids_matches_reference(hip, name):
+    """2-D node grids (the reference's `predict` takes any h x w; its mask is the Euclidean disc of src/imported/maskedatt.py:222-245):
+    frame-by-frame `predict` on [1,C,h,w] features and the batched `propagate_all(grid_w=w)` give the label maps the reference
+    produced; and random grids (radius larger than the grid, radius 1, non-square) against the oracle."""
+    from imported.labelprop import LabelPropVOS_CRW
+    g = load_golden(name)
+    h, w = (int(v) for v in g["grid"])
+    T, N, C = g["emb"].shape
+    M = int(g["nclasses"])
+    cfg = dict(CXT_SIZE=int(g["cxt_size"]), RADIUS=int(g["radius"]), TEMP=float(g["temp"]), KNN=int(g["knn"]))
+    feats = hip.normalize(dev(g["emb"]))
+    seed = dev(g["seed_labels"])
+    pred_all, L = LabelPropVOS_CRW(cfg).propagate_all(feats, seed, M, grid_w=w)
+    assert np.array_equal(pred_all.cpu().numpy(), g["pred"])
+    lp = LabelPropVOS_CRW(cfg)
+    as_feat = lambda n: feats[n].t().reshape(1, C, h, w)
+    fl = [as_feat(0)]
+    ml = [(seed[None, :] == torch.arange(M).cuda()[:, None]).float().reshape(1, M, h, w)]
+    for n in range(1, T):
+        m = lp.predict(fl, ml, as_feat(n))
+        assert m.shape == (1, M, h, w)
+        torch.testing.assert_close(m.reshape(M, N).t(), L[n * N:(n + 1) * N], rtol=0, atol=0)
+        assert np.array_equal(m.argmax(1).flatten().cpu().numpy(), g["pred"][:, n])
+        fl.append(as_feat(n))
+        ml.append(m)
+    assert lp.mask.shape == (1, N, N) and lp.mask_hw == (h, w)
+    assert np.array_equal(lp.mask[0].cpu().numpy(), orc.band_bias(N, cfg["RADIUS"], grid_w=w))
+    for (T2, h2, w2, C2, M2, cxt, radius, knn) in ((7, 5, 7, 12, 3, 2, 9, 6), (6, 4, 4, 8, 2, 10, 1, 3), (9, 3, 11, 20, 4, 3, 3, 8)):
+        gen = torch.Generator().manual_seed(h2 * 10 + w2)
+        emb = (torch.randn(1, h2 * w2, C2, generator=gen) + 0.4 * torch.randn(T2, h2 * w2, C2, generator=gen)).float()
+        sd = (torch.arange(h2 * w2) // w2 * M2 // h2).float()
+        ref = orc.labelprop(emb.numpy(), sd.numpy(), M2, cxt, radius, 0.1, knn, grid_w=w2)
+        got, _ = LabelPropVOS_CRW(dict(CXT_SIZE=cxt, RADIUS=radius, TEMP=0.1, KNN=knn)).propagate_all(hip.normalize(emb.cuda()), sd.cuda(), M2, grid_w=w2)
+        assert np.array_equal(got.cpu().numpy(), ref), (h2, w2, radius)
+
+
 @pytest.mark.parametrize("T,N,C,M,cxt,radius,knn,temp", [(10, 12, 16, 3, 3, 2, 5, 0.1),    # knn > in-band keys of the first frames
                                                          (9, 7, 10, 2, 2, 1, 3, 0.05),    # radius 1: only the same node is in band
                                                          (30, 20, 24, 4, 5, 30, 20, 0.2),  # radius > N: no mask at all, knn = N

@@ -95,3 +95,18 @@ def test_dataset_unfold_matches_reference(name):
     assert nw == int(g["n_items"])
     for i, idx in enumerate(g["picks"]):
         assert np.array_equal(orc.unfold_item(g["rg"], int(idx), L, dim, ov), g["items"][i])
+
+
+@pytest.mark.parametrize("name", ["labelprop_grid_T10_6x5", "labelprop_grid_T8_4x9"])
+def test_labelprop_on_2d_grids_matches_reference(name):
+    """The reference's LabelPropVOS_CRW.predict accepts any h x w node grid (src/imported/labelprop.py:67-115; Euclidean-radius mask
+    src/imported/maskedatt.py:222-245), although a radargram only ever produces N x 1: the oracle with `grid_w` against label
+    maps the reference produced on 6 x 5 and 4 x 9 grids."""
+    g = load_golden(name)
+    h, w = (int(v) for v in g["grid"])
+    pred = orc.labelprop(g["emb"], g["seed_labels"], int(g["nclasses"]), int(g["cxt_size"]), int(g["radius"]), float(g["temp"]),
+                         int(g["knn"]), grid_w=w)
+    assert pred.shape == (h * w, g["emb"].shape[0])
+    assert np.array_equal(pred, g["pred"])
+    # grid_w = 1 on the same node count is a different mask: the test would notice a grid that is ignored
+    assert not np.array_equal(orc.band_bias(h * w, int(g["radius"])), orc.band_bias(h * w, int(g["radius"]), grid_w=w))

@@ -56,3 +56,35 @@ for k in stats["torch64"]:
         i = int(d.argmax())
         line += f"  {tag}: {float(d.max()):.2e} (mean^2/var {float(mean[i] ** 2 / var[i]):.1e}, var {float(var[i]):.2e})"
     print(line)
+
+# conditioning probe: the fp64 modules with the fixture's dLoss/dEmb injected; how much do the gradients move when (a) the injected
+# gradient, (b) the input patches carry relative noise of 1e-6 (about what fp32 arithmetic leaves in them)?
+demb = torch.as_tensor(g["demb"]).cuda().double()
+
+
+def grads64(xin, gout):
+    m = copy.deepcopy(base).double()
+    m.hip_convs = None
+    m.train(True)
+    m(xin).backward(gout)
+    return {k: p.grad.flatten().cpu() for k, p in m.named_parameters()}
+
+
+gen = torch.Generator(device="cuda").manual_seed(1)
+ref64 = grads64(x.double(), demb)
+pa = grads64(x.double(), demb * (1 + 1e-6 * torch.randn(demb.shape, generator=gen, device="cuda", dtype=torch.float64)))
+pb = grads64(x.double() * (1 + 1e-6 * torch.randn(x.shape, generator=gen, device="cuda", dtype=torch.float64)), demb)
+pc = grads64(x.double(), demb.float().double())
+print("fp64 modules, fixture's demb injected: relative change of the gradient under 1e-6 relative noise on (a) demb, (b) the patches; (c) demb rounded to fp32")
+for k in ("model.fc.weight", "model.layer4.0.bn2.bias", "model.layer2.0.downsample.0.weight", "model.layer1.0.conv1.weight", "model.conv1.weight", "bn0.weight"):
+    r = ref64[k]
+    print(f"   {k:40s} (a) {float((pa[k] - r).norm() / r.norm()):.2e}  (b) {float((pb[k] - r).norm() / r.norm()):.2e}  (c) {float((pc[k] - r).norm() / r.norm()):.2e}"
+          f"   vs fixture {float((out['fixture'][k] - r).norm() / r.norm()) if k in out['fixture'] else float('nan'):.2e}")
+# the same injected gradient through the HIP kernels and through PyTorch-ROCm fp32
+for tag, conv in (("hip", "bf16x3"), ("torch32", None)):
+    m = copy.deepcopy(base)
+    m.hip_convs = conv
+    m.train(True)
+    m(x).backward(demb.float())
+    print(f"   {tag} (fp32, demb injected) vs fp64:", {k: f"{float((p.grad.double().flatten().cpu() - ref64[k]).norm() / ref64[k].norm()):.2e}"
+                                                       for k, p in m.named_parameters() if k in ("model.fc.weight", "model.layer1.0.conv1.weight", "model.conv1.weight")})
