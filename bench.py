@@ -758,16 +758,16 @@ def main():
             stored = rec.get("duration_us")
             if not stored:
                 return False
-            ok = abs(k["launch_us"] - stored) <= 0.05 * stored
+            ok = abs(k["launch_us"] - stored) <= 0.10 * stored  # (boxes of one round differ by +-3-4 %; a changed kernel moves more or not at all)
             if not ok:
                 k["traffic"] = None
                 k["traffic_note"] = (f"committed PMC constants NOT attached: live in-step launch time {k['launch_us']:.1f} us differs by more "
-                                     f"than 5 % from the {stored} us recorded with them (profiles/r03_pmc_in_step.json) -- re-run "
-                                     "tools/r03_pmc_cnn.sh + tools/pmc_report.py")
+                                     f"than 10 % from the {stored} us recorded with them (profiles/r04_pmc_in_step.json) -- re-run "
+                                     "tools/r04_pmc_cnn.sh + tools/pmc_report.py")
             return ok
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_in_step_traffic.json")))["kernels"]
-            dur = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_in_step.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_in_step_traffic.json")))["kernels"]
+            dur = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_in_step.json")))["kernels"]
             for k in kernels:
                 m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
                 if not m or args.convs != "bf16x3" or B * T * N != 16128:  # the passes ran at the default workload
@@ -779,12 +779,12 @@ def main():
                        f"conv3x3_kernel<3, {cin}, {cout}, 0, 8, false, 7>")
                 if key in pmc and pmc_fresh(k, dur.get(key, {})):
                     k["traffic"] = pmc[key]["hbm_bytes"]
-                    k["traffic_note"] = ("HBM bytes per launch INSIDE the step, committed PMC passes profiles/r03_pmc_in_step_traffic.json: "
+                    k["traffic_note"] = ("HBM bytes per launch INSIDE the step, committed PMC passes profiles/r04_pmc_in_step_traffic.json: "
                                          "reads = 2*1024*FETCH_SIZE (gfx950 correction) + writes = 1024*WRITE_SIZE; read/algorithmic = "
                                          f"{pmc[key]['read_over_algorithmic']}"
                                          + (f", write/algorithmic = {pmc[key]['write_over_algorithmic']}"
                                             if "write_over_algorithmic" in pmc[key] else ""))
-            util = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_in_step.json")))["kernels"]
+            util = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_in_step.json")))["kernels"]
             for k in kernels:
                 m = re.search(r"cin=(\d+) cout=(\d+)", k["kernel"])
                 if not m or args.convs != "bf16x3" or B * T * N != 16128:
@@ -797,7 +797,7 @@ def main():
                 if key in util and pmc_fresh(k, util[key]):
                     k["pmc_mfma_pipe_occupancy"] = util[key]["mfma_pipe_occupancy"]
                     k["pmc_effective_clock_GHz"] = util[key]["effective_clock_GHz"]
-                    k["pmc_note"] = ("committed PMC pass over this same command (profiles/r03_pmc_in_step.json): "
+                    k["pmc_note"] = ("committed PMC pass over this same command (profiles/r04_pmc_in_step.json): "
                                      "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) and the clock the chip held "
                                      "under this kernel inside the step (nominal 2.4 GHz)")
         except Exception:
