@@ -753,7 +753,7 @@ def main():
                             "note": "launch-latency bound at the reference-default node count"})
         # HBM traffic per launch from the committed PMC passes over this same command (rocprofv3 cannot run inside bench).  The
         # constants are keyed by kernel NAME, so they would go stale silently when a kernel changes and keeps its name: they are
-        # attached only where the live in-step event time of the kernel is within 5 % of the duration recorded beside them.
+        # attached only where the live in-step event time of the kernel is within 10 % of the duration recorded beside them.
         def pmc_fresh(k, rec):
             stored = rec.get("duration_us")
             if not stored:

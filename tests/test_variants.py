@@ -23,6 +23,12 @@ VARIANTS = [
     ("CRW_FRONT_NT", "1024", PARITY, "encoder_front_kernels or encoder_inference_trunk"),
     # bf16 chain GEMM with its A operand staged through registers (csrc/gemm_bf16.hip)
     ("CRW_GEMM_REGA", "1", PARITY, "gemm_bf16"),
+    # plain-bf16 256 x 256 chain GEMM on the ring of five 32-deep half-tiles (opt-in, csrc/gemm_bf16.hip mainloop_ring5), incl. n = 4096
+    ("CRW_GEMM_RING5", "1", PARITY + " tests/test_k_shape.py", "gemm_bf16 or bf16_chain_modes_on_256 or (walk_n4096 and 1-4)"),
+    # the round-3 hand-off of the sums-with-tail kernels (relaxed atomics behind s_waitcnt) and the acq_rel form: A/B partners of the
+    # default release + acquire fence (csrc/resnet_bn.hip rn_sums_tail_kernel)
+    ("CRW_RN_TICKET", "relaxed", RESNET, "native_and_stepwise or training_step or reproducible"),
+    ("CRW_RN_TICKET", "acqrel", RESNET, "native_and_stepwise or reproducible"),
 ]
 
 
@@ -30,7 +36,8 @@ VARIANTS = [
 @pytest.mark.parametrize("name,value,path,expr", VARIANTS, ids=[f"{v[0]}={v[1]}" for v in VARIANTS])
 def test_kernel_variant_behind_env_switch(name, value, path, expr):
     env = dict(os.environ, **{name: value})
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, path), "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider"],
+    r = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, p_) for p_ in path.split()], "-x", "-q", "-m", "gpu", "-k", expr,
+                        "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
