@@ -212,6 +212,25 @@ def resnet_event_kernels(ev, P, steps):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_resnet.json")))["by_grid"]
         Ppad = (P + 127) // 128 * 128
+        for k in out:  # weight gradients: the instance is named by the tile, its layers told apart by their time
+            key = k.get("_key")
+            if not key or key[0] != "rn_wgrad" or key[1] != crw_hip.RN_FWD:
+                continue
+            _, _, Hin, Win, Cin, Hout, Wout, Cout, kk, stride, pad = key
+            name = f"crw::rn_wgrad_kernel<{128 if Cin % 128 == 0 else 64}, {128 if Cout % 128 == 0 else 64}, 32>"
+            red = pmc.get("crw::rn_wgrad_reduce_kernel", {})
+            red_us = min((v["us_per_launch"] for v in red.values()), default=12.0)  # the slab sum inside the event bracket (smallest: a lower bound)
+            cands = [(abs(v["us_per_launch"] + red_us - k["launch_us"]), g_, v) for g_, v in pmc.get(name, {}).items()]
+            if not cands:
+                continue
+            d, grid, rec = min(cands)
+            if d <= 0.12 * k["launch_us"]:
+                k["traffic"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+                k["traffic_note"] = (f"HBM bytes per launch of the weight-gradient kernel inside the step (its slab sum not included), committed PMC "
+                                     f"passes profiles/r04_pmc_resnet.json ({name}, grid {grid}, {rec['us_per_launch']} us): reads 2*1024*FETCH_SIZE = "
+                                     f"{rec['hbm_read_bytes_per_launch'] / 1e6:.1f} MB (gfx950 correction), writes 1024*WRITE_SIZE = "
+                                     f"{rec['hbm_write_bytes_per_launch'] / 1e6:.1f} MB (the slabs); algorithmic: "
+                                     f"{k['algorithmic_bytes_per_launch'] / 1e6:.1f} MB (both operands' planes once)")
         for k in out:
             key = k.get("_key")
             if not key or key[0] != "rn_conv" or key[1] not in (crw_hip.RN_FWD, crw_hip.RN_BWD):
