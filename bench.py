@@ -208,7 +208,7 @@ def resnet_event_kernels(ev, P, steps):
     # HBM traffic per launch from the committed in-step PMC passes over this same command (rocprofv3 cannot run inside bench):
     # profiles/r04_pmc_resnet.json, "by_grid" = per (kernel instance, grid size) -- the grid tells the layers of one instance apart
     # (gathered product: blocks = patch tiles x column tiles x groups, 512 threads each).  Constants are attached only while the
-    # kernel still takes the time recorded with them (within 10 %).
+    # kernel's live time is compatible with the one recorded with them (see below).
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_resnet.json")))["by_grid"]
         Ppad = (P + 127) // 128 * 128
@@ -224,7 +224,7 @@ def resnet_event_kernels(ev, P, steps):
             if not cands:
                 continue
             d, grid, rec = min(cands)
-            if d <= 0.12 * k["launch_us"]:
+            if 0.9 * (rec["us_per_launch"] + red_us) <= k["launch_us"] <= 2.2 * (rec["us_per_launch"] + red_us):
                 k["traffic"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
                 k["traffic_note"] = (f"HBM bytes per launch of the weight-gradient kernel inside the step (its slab sum not included), committed PMC "
                                      f"passes profiles/r04_pmc_resnet.json ({name}, grid {grid}, {rec['us_per_launch']} us): reads 2*1024*FETCH_SIZE = "
@@ -243,7 +243,9 @@ def resnet_event_kernels(ev, P, steps):
             if not cands:
                 continue
             d, name, rec = min(cands)
-            if d <= 0.10 * rec["us_per_launch"]:
+            # (counter collection serialises the dispatches: the time recorded beside the counters is the kernel ALONE, the live event
+            # time includes whatever the side stream runs beside it -- anything from 0.9x to 2.2x of the recorded time is the same kernel)
+            if 0.9 * rec["us_per_launch"] <= k["launch_us"] <= 2.2 * rec["us_per_launch"]:
                 k["traffic"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
                 k["traffic_note"] = (f"HBM bytes per launch inside the step, committed PMC passes profiles/r04_pmc_resnet.json ({name}, grid {grid}: "
                                      f"reads 2*1024*FETCH_SIZE = {rec['hbm_read_bytes_per_launch'] / 1e6:.1f} MB (gfx950 correction), writes "
