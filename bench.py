@@ -220,10 +220,13 @@ def resnet_event_kernels(ev, P, steps):
             name = f"crw::rn_wgrad_kernel<{128 if Cin % 128 == 0 else 64}, {128 if Cout % 128 == 0 else 64}, 32>"
             red = pmc.get("crw::rn_wgrad_reduce_kernel", {})
             red_us = min((v["us_per_launch"] for v in red.values()), default=12.0)  # the slab sum inside the event bracket (smallest: a lower bound)
-            cands = [(abs(v["us_per_launch"] + red_us - k["launch_us"]), g_, v) for g_, v in pmc.get(name, {}).items()]
-            if not cands:
+            kh, kw = (kk >> 8, kk & 255) if kk >= 256 else (kk, kk)
+            slabs = crw_hip.lib().crw_rn_wgrad_ws_bytes(key[1], P, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad) // (Cin * Cout * 4)
+            tm, tn = (128 if Cin % 128 == 0 else 64), (128 if Cout % 128 == 0 else 64)
+            grid = str(slabs * (Cin // tm) * (Cout // tn) * 256)  # slabs = patch slices x live taps; one 256-thread block per slab tile
+            rec = pmc.get(name, {}).get(grid)
+            if rec is None:
                 continue
-            d, grid, rec = min(cands)
             if 0.9 * (rec["us_per_launch"] + red_us) <= k["launch_us"] <= 2.2 * (rec["us_per_launch"] + red_us):
                 k["traffic"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
                 k["traffic_note"] = (f"HBM bytes per launch of the weight-gradient kernel inside the step (its slab sum not included), committed PMC "
