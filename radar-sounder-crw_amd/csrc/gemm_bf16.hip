@@ -169,10 +169,16 @@ constexpr size_t ring_bytes() { return (size_t)ring_stages<SPLIT, TB>() * ((SPLI
 //   1 = MFMAs alone (fragments read once, before the loop)      2 = + the LDS fragment reads of every k-step
 //   3 = + the barrier (and its waits) per k-tile                 4 = + the LDS-DMA stream: the whole loop (= 0)
 //   5 = the LDS-DMA stream alone with its waits (no reads, no MFMAs, no barrier)      6 = DMA stream + barrier
+//   8 = NOT a diagnostic: the whole loop with the LDS-DMA requests of half the waves moved behind the first half of the k-tile's
+//       MFMAs (CRW_GEMM_STAGGER=1).  The barrier lines all eight waves up, so the two waves of a SIMD issue their 8 requests each
+//       (60-180 issue cycles apiece) at the same moment and the matrix pipe waits; staggered, one wave of a SIMD requests while the
+//       other multiplies.
+constexpr bool diag_stagger(int d) { return d == 8; }
+constexpr bool diag_timing(int d) { return d != 0 && d != 8; }
 constexpr bool diag_dma(int d) { return d == 0 || d >= 4; }
-constexpr bool diag_barrier(int d) { return d == 0 || d == 3 || d == 4 || d == 6; }
-constexpr bool diag_reads(int d) { return d == 0 || (d >= 2 && d <= 4); }
-constexpr bool diag_mfma(int d) { return d <= 4; }
+constexpr bool diag_barrier(int d) { return d == 0 || d == 3 || d == 4 || d == 6 || d == 8; }
+constexpr bool diag_reads(int d) { return d == 0 || (d >= 2 && d <= 4) || d == 8; }
+constexpr bool diag_mfma(int d) { return d <= 4 || d == 8; }
 
 template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA, int DIAG = 0>
 __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0,
@@ -210,7 +216,7 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
   }
   // (DIAG builds without the DMA stream or without fragment reads in the loop: both buffers hold real tiles, fragments of tile 0)
   bf8 dg_b[C::FN], dg_bl[C::FN], dg_a[4], dg_al[4];
-  if constexpr (DIAG != 0) {
+  if constexpr (diag_timing(DIAG)) {
     if (nt > 1 && NSTAGE == 2) stage(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -241,7 +247,7 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
         __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (diag_dma(DIAG)) {
-      if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+      if (t + NSTAGE - 1 < nt && (!diag_stagger(DIAG) || wave < C::WAVES / 2)) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
     }
     const char *base = lds + (t % NSTAGE) * NIMG * IMG;
 #pragma unroll
@@ -288,6 +294,13 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
               }
               acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i0 + i][j], 0, 0, 0);
             }
+          if constexpr (diag_stagger(DIAG)) {
+            // the second half of the waves requests tile t + 1 here: after the first k-step (BK = 64) / the first group of row tiles
+            // (BK = 32) -- the SIMD's other wave keeps the matrix pipe busy meanwhile
+            constexpr bool mid = (BKB / 32 == 2) ? true : false;
+            if ((mid ? (s == 0 && i0 + AG >= C::FM) : (i0 == 0)) && wave >= C::WAVES / 2 && t + NSTAGE - 1 < nt)
+              stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+          }
         } else if constexpr (diag_reads(DIAG)) {  // (no MFMAs: keep the fragment reads alive)
 #pragma unroll
           for (int i = 0; i < AG; ++i) asm volatile("" ::"v"(a[i]), "v"(al[i]));
@@ -484,8 +497,22 @@ inline bool ring5_on() {
   return on;
 }
 
+// CRW_GEMM_STAGGER=1: 256 x 256 tiles with the DMA requests of half the waves moved into the k-tile (mainloop, DIAG 8)
+inline bool stagger_on() {
+  static const bool on = [] { const char *e = getenv("CRW_GEMM_STAGGER"); return e && e[0] == '1'; }();
+  return on;
+}
+
 template <int SPLIT, int TB>
 int launch_layout(const GemmGroup &g, int code, hipStream_t s) {
+  if constexpr (TB == 256) {
+    if (stagger_on() && !rega_on()) switch (code) {
+        case 3: return launch_one<SPLIT, TB, true, true, false, 8>(g, s);
+        case 2: return launch_one<SPLIT, TB, true, false, false, 8>(g, s);
+        case 1: return launch_one<SPLIT, TB, false, true, false, 8>(g, s);
+        default: return launch_one<SPLIT, TB, false, false, false, 8>(g, s);
+      }
+  }
   if constexpr (SPLIT == 1 && TB == 256) {
     if (ring5_on() && !rega_on()) switch (code) {
         case 3: return launch_one<SPLIT, TB, true, true, false, 0, true>(g, s);
