@@ -173,12 +173,13 @@ constexpr size_t ring_bytes() { return (size_t)ring_stages<SPLIT, TB>() * ((SPLI
 //       MFMAs (CRW_GEMM_STAGGER=1).  The barrier lines all eight waves up, so the two waves of a SIMD issue their 8 requests each
 //       (60-180 issue cycles apiece) at the same moment and the matrix pipe waits; staggered, one wave of a SIMD requests while the
 //       other multiplies.
-constexpr bool diag_stagger(int d) { return d == 8; }
-constexpr bool diag_timing(int d) { return d != 0 && d != 8; }
+//   9 = the same with the second half's requests after the FIRST QUARTER of the k-tile (BK = 64 only; more time to land)
+constexpr bool diag_stagger(int d) { return d == 8 || d == 9; }
+constexpr bool diag_timing(int d) { return d != 0 && d != 8 && d != 9; }
 constexpr bool diag_dma(int d) { return d == 0 || d >= 4; }
-constexpr bool diag_barrier(int d) { return d == 0 || d == 3 || d == 4 || d == 6 || d == 8; }
-constexpr bool diag_reads(int d) { return d == 0 || (d >= 2 && d <= 4) || d == 8; }
-constexpr bool diag_mfma(int d) { return d <= 4 || d == 8; }
+constexpr bool diag_barrier(int d) { return d == 0 || d == 3 || d == 4 || d == 6 || d == 8 || d == 9; }
+constexpr bool diag_reads(int d) { return d == 0 || (d >= 2 && d <= 4) || d == 8 || d == 9; }
+constexpr bool diag_mfma(int d) { return d <= 4 || d == 8 || d == 9; }
 
 template <int SPLIT, int TB, bool AKC, bool BKC, bool REGA, int DIAG = 0>
 __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperand A, BfOperand B, int n, int m0,
@@ -297,8 +298,9 @@ __device__ inline void mainloop(f32x4 (&acc)[Cfg<TB>::FM][Cfg<TB>::FN], BfOperan
           if constexpr (diag_stagger(DIAG)) {
             // the second half of the waves requests tile t + 1 here: after the first k-step (BK = 64) / the first group of row tiles
             // (BK = 32) -- the SIMD's other wave keeps the matrix pipe busy meanwhile
-            constexpr bool mid = (BKB / 32 == 2) ? true : false;
-            if ((mid ? (s == 0 && i0 + AG >= C::FM) : (i0 == 0)) && wave >= C::WAVES / 2 && t + NSTAGE - 1 < nt)
+            constexpr bool two_steps = BKB / 32 == 2;
+            const bool here = (two_steps && DIAG == 9) ? (s == 0 && i0 == 0) : (two_steps ? (s == 0 && i0 + AG >= C::FM) : (i0 == 0));
+            if (here && wave >= C::WAVES / 2 && t + NSTAGE - 1 < nt)
               stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
           }
         } else if constexpr (diag_reads(DIAG)) {  // (no MFMAs: keep the fragment reads alive)
@@ -497,16 +499,26 @@ inline bool ring5_on() {
   return on;
 }
 
-// CRW_GEMM_STAGGER=1: 256 x 256 tiles with the DMA requests of half the waves moved into the k-tile (mainloop, DIAG 8)
-inline bool stagger_on() {
-  static const bool on = [] { const char *e = getenv("CRW_GEMM_STAGGER"); return e && e[0] == '1'; }();
+// 256 x 256 tiles: the LDS-DMA requests of half the waves (one of each SIMD's pair) are moved behind the first half of the k-tile's
+// MFMAs (mainloop, DIAG 8) -- the default since round 4: plain bf16 +4-7 % in all four operand layouts at n = 4096 (988 -> 1031,
+// 1003 -> 1054, 946 -> 1018, 968 -> 1032 TFLOP/s), hi/lo pairs +1 %, the whole N = 4096 walk 45.2 -> 43.9 ms
+// (profiles/r04_gemm_stagger.log).  CRW_GEMM_STAGGER=0: every wave requests right behind the barrier (rounds 1-3); 2: the second
+// half requests after the first QUARTER of the k-tile (equal within noise: profiles/r04_gemm_stagger.log).
+inline int stagger_on() {
+  static const int on = [] { const char *e = getenv("CRW_GEMM_STAGGER"); return e ? atoi(e) : 1; }();
   return on;
 }
 
 template <int SPLIT, int TB>
 int launch_layout(const GemmGroup &g, int code, hipStream_t s) {
   if constexpr (TB == 256) {
-    if (stagger_on() && !rega_on()) switch (code) {
+    if (stagger_on() == 2 && !rega_on()) switch (code) {
+        case 3: return launch_one<SPLIT, TB, true, true, false, 9>(g, s);
+        case 2: return launch_one<SPLIT, TB, true, false, false, 9>(g, s);
+        case 1: return launch_one<SPLIT, TB, false, true, false, 9>(g, s);
+        default: return launch_one<SPLIT, TB, false, false, false, 9>(g, s);
+      }
+    if (stagger_on() == 1 && !rega_on()) switch (code) {
         case 3: return launch_one<SPLIT, TB, true, true, false, 8>(g, s);
         case 2: return launch_one<SPLIT, TB, true, false, false, 8>(g, s);
         case 1: return launch_one<SPLIT, TB, false, true, false, 8>(g, s);

@@ -25,6 +25,10 @@ VARIANTS = [
     ("CRW_GEMM_REGA", "1", PARITY, "gemm_bf16"),
     # plain-bf16 256 x 256 chain GEMM on the ring of five 32-deep half-tiles (opt-in, csrc/gemm_bf16.hip mainloop_ring5), incl. n = 4096
     ("CRW_GEMM_RING5", "1", PARITY + " tests/test_k_shape.py", "gemm_bf16 or bf16_chain_modes_on_256 or (walk_n4096 and 1-4)"),
+    # 256 x 256 chain GEMM with every wave requesting its LDS-DMA right behind the barrier (rounds 1-3; the default staggers them), and
+    # with the second half of the waves requesting after a quarter of the k-tile
+    ("CRW_GEMM_STAGGER", "0", PARITY + " tests/test_k_shape.py", "gemm_bf16 or bf16_chain_modes_on_256 or (walk_n4096 and 1-4)"),
+    ("CRW_GEMM_STAGGER", "2", PARITY, "gemm_bf16"),
     # the round-3 hand-off of the sums-with-tail kernels (relaxed atomics behind s_waitcnt) and the acq_rel form: A/B partners of the
     # default release + acquire fence (csrc/resnet_bn.hip rn_sums_tail_kernel)
     ("CRW_RN_TICKET", "relaxed", RESNET, "native_and_stepwise or training_step or reproducible"),
