@@ -1,6 +1,7 @@
 // What bounds the bf16 transition-matrix chain GEMM (csrc/gemm_bf16.hip) at n = 4096?  This program times the library's OWN main loop
 // -- the file is included, not copied -- in its timing-only DIAG variants (parts of the loop left out; results meaningless):
-//     MFMAs alone  ->  + LDS fragment reads  ->  + barrier per k-tile  ->  + the LDS-DMA operand stream (= the shipped kernel)
+//     MFMAs alone  ->  + LDS fragment reads  ->  + barrier per k-tile  ->  + the LDS-DMA operand stream (= the whole loop of rounds 1-3;
+//     the library's default at 256 x 256 staggers the requests of the two waves of a SIMD: last row)
 // and the DMA stream alone / with the barrier, for every tile the kernel has (128 x 128 on 4 waves, two workgroups per CU;
 // 256 x 256 on 8 waves, one per CU), plain bf16 and hi/lo pairs, in the two operand layouts the chain uses most.
 // It prints MFMA flops executed per second (what bench.py's roofline_chain_n4096* lines quote) and the time per k-tile and CU.
@@ -19,8 +20,8 @@ thread_local int g_last_hip_error = 0;
 }
 using namespace crw;
 
-static const char *MODE[] = {"shipped kernel", "MFMAs alone", "+ LDS fragment reads", "+ barrier per k-tile", "+ LDS-DMA stream (all)",
-                             "LDS-DMA stream alone", "LDS-DMA stream + barrier", "shipped kernel (again, last)"};
+static const char *MODE[] = {"whole loop, all request at barrier", "MFMAs alone", "+ LDS fragment reads", "+ barrier per k-tile", "+ LDS-DMA stream (all)",
+                             "LDS-DMA stream alone", "LDS-DMA stream + barrier", "whole loop (again, last)", "whole loop, staggered requests"};
 
 template <int SPLIT, int TB, bool AKC, bool BKC, int DIAG, bool RING5 = false>
 static double time_one(const GemmGroup &g, int iters) {
@@ -44,7 +45,7 @@ static void sweep(const GemmGroup &g, const char *layout) {
   const double flops = 2.0 * g.n * (double)g.n * g.n * g.batch * (SPLIT == 3 ? 3 : 1);
   const int bk = tile_bk<SPLIT, TB>();
   const double ktiles_per_cu = (double)(g.n / TB) * (g.n / TB) * g.batch * (g.n / bk) / 256.0;  // k-tiles a CU works through
-  double ms[8];
+  double ms[9];
   (void)time_one<SPLIT, TB, AKC, BKC, 0>(g, 40);  // warm-up: the chip settles into the clock it holds under this kernel
   ms[0] = time_one<SPLIT, TB, AKC, BKC, 0>(g, 10);
   ms[1] = time_one<SPLIT, TB, AKC, BKC, 1>(g, 10);
@@ -54,12 +55,13 @@ static void sweep(const GemmGroup &g, const char *layout) {
   ms[5] = time_one<SPLIT, TB, AKC, BKC, 5>(g, 10);
   ms[6] = time_one<SPLIT, TB, AKC, BKC, 6>(g, 10);
   ms[7] = time_one<SPLIT, TB, AKC, BKC, 0>(g, 10);
+  ms[8] = TB == 256 ? time_one<SPLIT, TB, AKC, BKC, 8>(g, 10) : 0.0;  // the library's default at 256 x 256 since round 4
   const double stage_kb = (SPLIT == 3 ? 4 : 2) * TB * 2.0 * bk / 1024.0;
   printf("tile %3d x %3d, BK %2d, %s, %s  (%.0f KiB of operands per k-tile, %d workgroup(s) per CU)\n", TB, TB, bk,
          SPLIT == 3 ? "hi/lo pairs (3 MFMAs per product)" : "plain bf16", layout, stage_kb, TB == 128 && SPLIT == 1 ? 2 : 1);
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < (TB == 256 ? 9 : 8); ++m) {
     const double us_tile = ms[m] * 1e3 / ktiles_per_cu;
-    if (m <= 4 || m == 7)
+    if (m <= 4 || m >= 7)
       printf("    %-28s %8.1f us/launch  %7.1f TFLOP/s executed = %.3f of 2500   %6.3f us per k-tile and CU\n", MODE[m], ms[m] * 1e3,
              flops / (ms[m] * 1e-3) / 1e12, flops / (ms[m] * 1e-3) / 1e12 / 2500.0, us_tile);
     else
