@@ -20,6 +20,8 @@
 //
 // HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of lane-linear images with the bank swizzle on the source
 // address, counted vmcnt + raw s_barrier -- the staging scheme of gemm_bf16.hip, here with gathered / strided operands.
+#include <algorithm>
+
 #include "crw_common.h"
 #include "resnet.h"
 
@@ -793,13 +795,16 @@ int launch_wgrad_cfg(const RnWgradArgs &a, hipStream_t s) {
   using C = TNCfg<TM, TN, BK_>;
   static bool attr_set = false;
   if (!attr_set) {
+    // (the deepest ring -- 128 x 128 tiles of 64 patches, the CRW_RN_WBK=64 A/B partner -- leaves 32 KB for the table: 4096 pairs fit
+    // the CU's 160 KB exactly once the attribute is clamped to it)
     if (hipFuncSetAttribute((const void *)rn_wgrad_kernel<TM, TN, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)C::lds(RN_MAXPAIR_CAP)) != hipSuccess) {
+                            (int)std::min(C::lds(RN_MAXPAIR_CAP), (size_t)160 * 1024)) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr_set = true;
   }
+  if (C::lds(a.maxpair) > (size_t)160 * 1024) return CRW_EINVAL;
   hipLaunchKernelGGL((rn_wgrad_kernel<TM, TN, BK_>), dim3(a.ntv * (a.Mtot / TM) * (a.Ntot / TN) * a.S), dim3(256), C::lds(a.maxpair), s, a);
   return check_launch();
 }
