@@ -49,7 +49,11 @@ CONVS = [  # Hin, Win, Cin, Cout, k, stride, pad
     # 32 x 32 patches (scripts/test/test_mc1.py:19): maps 9 -> 9 -> 5 -> 3 -> 2, then the head over the 2 x 2 map as ONE product whose
     # kernel covers the map (global average pool + linear, src/encoder.py:264-266); a 1 x 3 final map (16 x 80 patches) likewise
     (9, 9, 64, 64, 3, 1, 1), (9, 9, 64, 128, 3, 2, 1), (5, 5, 128, 256, 3, 2, 1), (3, 3, 256, 512, 3, 2, 1), (2, 2, 512, 512, 3, 1, 1),
-    (2, 2, 512, 128, (2, 2), 1, 0), (1, 3, 512, 128, (1, 3), 1, 0)]
+    (2, 2, 512, 128, (2, 2), 1, 0), (1, 3, 512, 128, (1, 3), 1, 0),
+    # the row-per-workgroup kernel of the 64 -> 64 layers (csrc/resnet_gemm.hip rn_conv_row_kernel): one-pixel / one-row / two-row maps,
+    # a row in three chunks, a chunk of one output
+    (1, 1, 64, 64, 3, 1, 1), (1, 7, 64, 64, 3, 1, 1), (2, 3, 64, 64, 3, 1, 1), (3, 11, 64, 64, 3, 1, 1), (6, 2, 64, 64, 3, 1, 1),
+    (3, 21, 64, 64, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("geo", CONVS)
