@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stand-alone timing of the first BasicBlock's 3x3 products at the bench batch (P = 16128, 5 x 5 x 64 -> 64): forward and
-backward-data through crw_rn_conv, alone on the chip (no side stream).  CRW_RN_ROW=0|1 selects the kernel (read once per process).
+backward-data through crw_rn_conv, alone on the chip (no side stream) -- the harness of profiles/r04_rn_row_experiment.log (run it
+under `rocprofv3 --kernel-trace --stats` for kernel durations; the event times below include the host's launch gaps).
 usage: python tools/r04_row_probe.py [P] [H] [W]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "radar-sounder-crw_amd"))
@@ -28,4 +29,4 @@ for mode, name, wq in ((H.RN_FWD, "fwd", wp[:2]), (H.RN_BWD, "bwd-data", wp[2:])
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
-        print(f"CRW_RN_ROW={os.environ.get('CRW_RN_ROW', '1')} {name:9s} stats={int(stats)} P={P} {Hm}x{Wm}: {us:7.1f} us/launch", flush=True)
+        print(f"{name:9s} stats={int(stats)} P={P} {Hm}x{Wm}: {us:7.1f} us/launch", flush=True)
