@@ -107,7 +107,9 @@ int crw_normalize(const float *emb, int rows, int C, float *ehat, float *norm, c
  * band |m-q| < radius, logits <key,query>/temp, softmax over the knn.
  * W [T-first_frame,knn,N] weights, I [same] int32 indices into the (truncated) key list.
  * Requires 1 <= radius, 1 <= knn <= 64. Slots beyond the number of in-band keys get weight 0
- * (the reference fills them with masked keys whose softmax weight is exactly 0). */
+ * (the reference fills them with masked keys whose softmax weight is exactly 0).
+ * Scores are exact fp32 products accumulated in fp32: on the fp32 matrix cores when N >= 16, C is 64, 128 or 256 and ehat is 16-byte
+ * aligned, else on the vector units -- the two differ in summation order only. */
 int crw_labelprop_topk(const float *ehat, int T, int N, int C, int cxt_size, int radius, float temp,
                        int knn, int first_frame, float *W, int32_t *I, crw_stream_t stream);
 /* The same on a 2-D node grid: the N nodes of a frame are an (N / grid_w) x grid_w grid in row-major order and the band is the

@@ -119,6 +119,174 @@ __global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__rest
   }
 }
 
+// ---- the same lists on an N x 1 grid (a radargram's patch column), scores on the fp32 matrix cores ------------------------------
+// The kernel above spends its time in vector arithmetic: 16 lanes per (query, key) pair, ~30 instructions for 128 multiply-adds.
+// Here a workgroup owns 16 consecutive query nodes of a frame; S = Q K^T for 16 keys at a time is 32 v_mfma_f32_16x16x4_f32 (exact
+// fp32 products, fp32 accumulation -- the summation order differs from the vector kernel's, as that one's differs from the
+// reference's BLAS), a wave per (context frame, 16-node key tile), the next tile's rows requested before this one's MFMAs.  In-band
+// scores go to LDS as val[query][candidate] in the reference's candidate order; selection: a wave per PAIR of queries with their candidates in
+// registers (TK_NV per lane and query) -- no workgroup barrier inside the knn rounds --, same rule: highest value, then lowest candidate index.
+constexpr int TK_Q = 16, TK_NV = 32, TK_NT = 512, TK_NW = TK_NT / 64;  // eight waves: two per SIMD cover each other's round trips
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int CSTEPS>  // C / 16: float4 per lane and row
+__global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float *__restrict__ ehat, int T, int N, int cxt, int radius, float temp,
+                                                                  int knn, int first_frame, int maxcand, float *__restrict__ W,
+                                                                  int32_t *__restrict__ I) {
+  constexpr int C = 16 * CSTEPS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *val = smem;  // [TK_Q][maxcand]
+  __shared__ float sel_v[TK_Q][MAX_KNN];
+  __shared__ int sel_i[TK_Q][MAX_KNN];
+  const int q0 = blockIdx.x * TK_Q, nq = min(TK_Q, N - q0), n = blockIdx.y + first_frame;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const bool trunc = n > cxt + 1;
+  const int nf = trunc ? cxt + 1 : n;
+
+  // A operand: query row q0 + r16 (rows beyond the column repeat the last node: their scores are never stored); lane group g holds
+  // elements 16 j + 4 g .. + 3 of every 16 -- the k order of the MFMA steps, the same for both operands
+  float4 a[CSTEPS];
+  {
+    const float *qp = ehat + ((long)n * N + min(q0 + r16, N - 1)) * C + 4 * g;
+#pragma unroll
+    for (int j = 0; j < CSTEPS; ++j) a[j] = *reinterpret_cast<const float4 *>(qp + 16 * j);
+  }
+  const int ulo = max(0, q0 - radius + 1), uhi = min(N - 1, q0 + nq - 1 + radius - 1);
+  const int kt_lo = ulo >> 4, nkt = (uhi >> 4) - kt_lo + 1, nitems = nf * nkt;  // item = (context frame p, key tile kt)
+  int lo_r[4], bw_r[4];  // bands of the four queries whose scores this lane receives (rows 4 g + r of the tile)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + 4 * g + r, lo = max(0, q - radius + 1), hi = min(N - 1, q + radius - 1);
+    lo_r[r] = lo;
+    bw_r[r] = q < N ? hi - lo + 1 : 0;
+  }
+  auto fetch = [&](int item, float4 (&b)[CSTEPS]) {
+    const int p = item / nkt, kt = kt_lo + item - p * nkt;
+    const int frame = trunc ? (p == 0 ? 0 : n - cxt + (p - 1)) : p;
+    const float *kp = ehat + ((long)frame * N + min(16 * kt + r16, N - 1)) * C + 4 * g;
+#pragma unroll
+    for (int j = 0; j < CSTEPS; ++j) b[j] = *reinterpret_cast<const float4 *>(kp + 16 * j);
+  };
+  float4 b[CSTEPS], bn[CSTEPS];
+  if (wave < nitems) fetch(wave, b);
+  for (int item = wave; item < nitems; item += TK_NW) {
+    if (item + TK_NW < nitems) fetch(item + TK_NW, bn);
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd steps: two independent chains
+#pragma unroll
+    for (int j = 0; j < CSTEPS; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc1, 0, 0, 0);
+    }
+    const int p = item / nkt, m = 16 * (kt_lo + item - p * nkt) + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = m - lo_r[r];
+      if (m < N && rr >= 0 && rr < bw_r[r]) val[(4 * g + r) * maxcand + p * bw_r[r] + rr] = (acc0[r] + acc1[r]) / temp;
+    }
+#pragma unroll
+    for (int j = 0; j < CSTEPS; ++j) b[j] = bn[j];
+  }
+  __syncthreads();
+
+  // selection: wave w takes the queries w and w + 8 TOGETHER -- two independent chains of compares / cross-lane exchanges in one
+  // instruction stream
+  {
+    const int u0 = wave, u1 = wave + TK_NW;
+    int lo2[2], bw2[2], nc2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = q0 + (h ? u1 : u0), lo = max(0, q - radius + 1), hi = min(N - 1, q + radius - 1);
+      lo2[h] = lo;
+      bw2[h] = hi - lo + 1;
+      nc2[h] = (h ? u1 : u0) < nq ? nf * bw2[h] : 0;
+    }
+    float v[2][TK_NV];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < TK_NV; ++i) {
+        const int c = lane + 64 * i;
+        v[h][i] = c < nc2[h] ? val[(h ? u1 : u0) * maxcand + c] : -INFINITY;
+      }
+    for (int j = 0; j < knn; ++j) {
+      float bv[2];
+      int bi[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float x = v[h][0];
+        int bs = 0;
+#pragma unroll
+        for (int i = 1; i < TK_NV; ++i)
+          if (v[h][i] > x) { x = v[h][i]; bs = i; }  // ties inside a lane: the lowest slot = the lowest candidate index
+        bv[h] = x;
+        bi[h] = x == -INFINITY ? 0x7fffffff : lane + 64 * bs;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float ov = __shfl_xor(bv[h], o);
+          const int oi = __shfl_xor(bi[h], o);
+          if (ov > bv[h] || (ov == bv[h] && oi < bi[h])) { bv[h] = ov; bi[h] = oi; }
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (lane == 0 && (h ? u1 : u0) < nq) {
+          sel_v[h ? u1 : u0][j] = bv[h];
+          sel_i[h ? u1 : u0][j] = bi[h];
+        }
+        if (bi[h] != 0x7fffffff && (bi[h] & 63) == lane) {
+          const int slot = bi[h] >> 6;
+#pragma unroll
+          for (int i = 0; i < TK_NV; ++i)
+            if (i == slot) v[h][i] = -INFINITY;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // lane 0's stores are in LDS before the wave reads them back
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int u = h ? u1 : u0;
+      if (u < nq && lane < knn) {
+        const float vmax = sel_v[u][0];  // the query's own node is always in its band (radius >= 1)
+        float ssum = 0.f;
+        for (int j = 0; j < knn; ++j) ssum += (sel_v[u][j] == -INFINITY) ? 0.f : expf(sel_v[u][j] - vmax);
+        const float x = sel_v[u][lane];
+        float w = 0.f;
+        int idx = 0;
+        if (x != -INFINITY) {
+          w = expf(x - vmax) / ssum;
+          const int c = sel_i[u][lane];
+          idx = (c / bw2[h]) * N + lo2[h] + c % bw2[h];
+        }
+        const long o = ((long)(n - first_frame) * knn + lane) * N + q0 + u;
+        W[o] = w;
+        I[o] = idx;
+      }
+    }
+  }
+}
+
+template <int CSTEPS>
+int launch_topk_mfma(const float *ehat, int T, int N, int cxt, int radius, float temp, int knn, int first_frame, int maxcand, float *W,
+                     int32_t *I, hipStream_t s) {
+  const size_t lds = (size_t)TK_Q * maxcand * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void *)labelprop_topk_mfma_kernel<CSTEPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+        hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      return CRW_EHIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(labelprop_topk_mfma_kernel<CSTEPS>, dim3((N + TK_Q - 1) / TK_Q, T - first_frame), dim3(TK_NT), lds, s, ehat, T, N, cxt,
+                     radius, temp, knn, first_frame, maxcand, W, I);
+  return check_launch();
+}
+
 __device__ inline float ld_l2(const float *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -312,6 +480,17 @@ int crw_labelprop_topk_grid(const float *ehat, int T, int N, int C, int cxt_size
   const long max_nf = (long)(cxt_size + 1 < T - 1 ? cxt_size + 1 : T - 1);
   const long max_bi = (2L * radius - 1 < gh) ? 2L * radius - 1 : gh, max_bj = (2L * radius - 1 < grid_w) ? 2L * radius - 1 : grid_w;
   const size_t lds = (((size_t)C + 3) & ~(size_t)3) * 4 + (size_t)(max_nf * max_bi * max_bj) * 4;
+  // a radargram's patch column with at least one full tile of queries: scores on the fp32 matrix cores (labelprop_topk_mfma_kernel).
+  // CRW_LABELPROP_TOPK_VALU=1 keeps the vector kernel (A/B)
+  static const bool valu = getenv("CRW_LABELPROP_TOPK_VALU") && getenv("CRW_LABELPROP_TOPK_VALU")[0] == '1';
+  const long maxcand = max_nf * max_bi;
+  if (grid_w == 1 && !valu && N >= TK_Q && (C == 64 || C == 128 || C == 256) && maxcand <= 64L * TK_NV &&
+      (size_t)TK_Q * maxcand * 4 <= 150 * 1024 && (((uintptr_t)ehat) & 15) == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64) return launch_topk_mfma<4>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)maxcand, W, I, s);
+    if (C == 128) return launch_topk_mfma<8>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)maxcand, W, I, s);
+    return launch_topk_mfma<16>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)maxcand, W, I, s);
+  }
   if (lds > 60 * 1024) return CRW_EINVAL;
   hipLaunchKernelGGL(labelprop_topk_kernel, dim3(N, T - first_frame), dim3(256), lds, (hipStream_t)stream, ehat, T,
                      N, C, cxt_size, radius, temp, knn, first_frame, grid_w, W, I);

@@ -19,15 +19,29 @@ import math
 import numpy as np
 
 
+_TRIU = {}
+
+
 def rbf_gram(signal, gamma=None):
     x = np.asarray(signal, dtype=np.float64).reshape(len(signal), -1)
-    d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
-    iu = np.triu_indices(len(x), 1)
+    n = len(x)
+    if x.shape[1] == 1:
+        d2 = x - x.T
+        d2 *= d2
+    else:
+        d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
     if gamma is None:
-        med = np.median(d2[iu]) if len(iu[0]) else 0.0
+        iu = _TRIU.get(n)
+        if iu is None:
+            iu = _TRIU[n] = np.triu_indices(n, 1)
+        v = np.sort(d2[iu])  # median of the pairwise squared distances (np.median's value: mean of the two middle elements)
+        m = len(v)
+        med = 0.0 if m == 0 else (v[m // 2] if m % 2 else (v[m // 2 - 1] + v[m // 2]) / 2.0)
         gamma = 1.0 / med if med != 0 else 1.0
-    k = np.clip(d2 * gamma, 1e-2, 1e2)
-    g = np.exp(-k)
+    d2 *= gamma
+    np.clip(d2, 1e-2, 1e2, out=d2)
+    np.negative(d2, out=d2)
+    g = np.exp(d2, out=d2)
     np.fill_diagonal(g, 1.0)
     return g
 
@@ -38,30 +52,38 @@ def pelt_rbf(signal, pen, min_size=2, jump=5, gamma=None):
     gram = rbf_gram(signal, gamma)
     # prefix sums: S[i, j] = sum of gram[:i, :j]  ->  block sums in O(1)
     S = np.zeros((n + 1, n + 1))
-    S[1:, 1:] = gram.cumsum(0).cumsum(1)
+    np.cumsum(np.cumsum(gram, axis=0), axis=1, out=S[1:, 1:])
     diag = np.concatenate([[0.0], np.cumsum(np.diagonal(gram))])
 
     def cost(a, b):
         block = S[b, b] - S[a, b] - S[b, a] + S[a, a]
         return (diag[b] - diag[a]) - block / (b - a)
 
-    # partitions[t] = (total penalised cost, breakpoints) of the best segmentation of signal[:t]
-    partitions = {0: (0.0, ())}
-    admissible = []
+    # total[t] = penalised cost of the best segmentation of signal[:t], prev[t] = its last change position (-1: none yet).  The
+    # admissible last-change positions of one end point are costed in ONE vectorised expression (same arithmetic per element as
+    # cost() above; np.argmin takes the first minimum, as min() over the list did)
+    total = np.full(n + 1, np.inf)
+    prev = np.full(n + 1, -1, dtype=np.int64)
+    total[0] = 0.0
+    Sd = np.diagonal(S)
+    admissible = np.zeros(0, dtype=np.int64)
     ends = [k for k in range(0, n, jump) if k >= min_size] + [n]
     for bkp in ends:
-        admissible.append(int(math.floor((bkp - min_size) / jump)) * jump)
-        cand = []
-        for t in admissible:
-            if t not in partitions or bkp - t < min_size:
-                continue
-            total, bk = partitions[t]
-            cand.append((total + cost(t, bkp) + pen, bk + (bkp,), t))
-        if not cand:
+        admissible = np.append(admissible, int(math.floor((bkp - min_size) / jump)) * jump)
+        t = admissible[np.isfinite(total[admissible]) & (bkp - admissible >= min_size)]
+        if t.size == 0:
             continue
-        best = min(cand, key=lambda c: c[0])
-        partitions[bkp] = (best[0], best[1])
-        admissible = [t for total, _, t in cand if total <= best[0] + pen]  # PELT pruning
-    if n not in partitions:
+        block = S[bkp, bkp] - S[t, bkp] - S[bkp, t] + Sd[t]
+        cand = total[t] + ((diag[bkp] - diag[t]) - block / (bkp - t)) + pen
+        k = int(np.argmin(cand))
+        total[bkp] = cand[k]
+        prev[bkp] = t[k]
+        admissible = t[cand <= cand[k] + pen]  # PELT pruning
+    if not np.isfinite(total[n]):
         return [n]
-    return sorted(partitions[n][1])
+    bkps = []
+    t = n
+    while t > 0:
+        bkps.append(int(t))
+        t = int(prev[t])
+    return sorted(bkps)

@@ -869,6 +869,31 @@ def test_labelprop_edge_cases_match_oracle(hip, T, N, C, M, cxt, radius, knn, te
     assert np.array_equal(pred.cpu().numpy(), ref), f"{(pred.cpu().numpy() != ref).sum()} of {ref.size} labels differ"
 
 
+@pytest.mark.parametrize("T,N,C,cxt,radius,knn,first", [
+    (256, 48, 128, 80, 10, 20, 1),  # BASELINE config 5
+    (40, 21, 64, 6, 4, 9, 1),       # node count not a multiple of the 16-query tile; truncated context
+    (12, 16, 128, 20, 30, 64, 1),   # radius larger than the column, more neighbours asked for than there are candidates
+    (30, 37, 256, 5, 1, 3, 4),      # radius 1 (the query's own node only), 256 channels, later first frame
+    (70, 100, 128, 9, 17, 12, 1)])  # three key tiles per query tile and more
+def test_labelprop_topk_on_matrix_cores_agrees_with_vector_kernel(hip, T, N, C, cxt, radius, knn, first):
+    """A radargram's column (N x 1 grid, N >= 16, C = 64 / 128 / 256) scores on the fp32 matrix cores
+    (csrc/labelprop.hip labelprop_topk_mfma_kernel); a 1 x N grid is the same problem -- same candidates in the same order -- and runs
+    the vector kernel.  Exact fp32 products in both, different summation order: the lists must agree except where two candidates
+    score within rounding of each other (then they carry the same weight to 1e-6), and the scores against fp64."""
+    g = torch.Generator().manual_seed(T + N)
+    feats = hip.normalize((torch.randn(1, N, C, generator=g) + 0.5 * torch.randn(T, N, C, generator=g)).float().cuda())
+    Wm, Im = hip.labelprop_topk(feats, cxt, radius, 0.1, knn, first_frame=first, grid_w=1)
+    Wv, Iv = hip.labelprop_topk(feats, cxt, radius, 0.1, knn, first_frame=first, grid_w=N)
+    torch.testing.assert_close(Wm, Wv, rtol=2e-5, atol=1e-6)
+    differ = Im != Iv
+    assert differ.float().mean().item() < 1e-3, f"{differ.sum().item()} of {differ.numel()} neighbours differ"
+    # a swapped pair holds two near-equal scores: the weights at those positions agree (checked above); every list is a set of
+    # distinct candidates with weights in descending order
+    assert (Wm[:, :-1] >= Wm[:, 1:] - 1e-7).all()
+    ws = Wm.sum(1)
+    torch.testing.assert_close(ws, torch.ones_like(ws), rtol=1e-5, atol=1e-5)
+
+
 def test_labelprop_matches_oracle_mcords_shape(hip):
     """BASELINE config 5 shape [T,N] = [256,48] with truncation (CXT_SIZE=80)."""
     from imported.labelprop import LabelPropVOS_CRW
