@@ -463,6 +463,44 @@ __global__ __launch_bounds__(64) void xent_metric_kernel(const float *__restrict
   if (lane == 0) xent[(long)a * (T - 1) + i] = (logf(s) + m) - col[a];
 }
 
+// The same metric with a workgroup per FRAME: the frame's features sit in LDS twice (as they are, and shifted by one channel, so both
+// operands of a pair are read as aligned float4), every thread takes N * N / 256 (c, a) pairs, then a thread per column does the
+// log-sum-exp.  12240 one-wave workgroups with 48 serial wave reductions each took 92 us at cfg5 -- on the way to the host's
+// change-point search, which is the tail of that step.
+constexpr int XENT_NT = 256;
+__global__ __launch_bounds__(XENT_NT) void xent_metric_frame_kernel(const float *__restrict__ ehat, int T, int N, int C, float *__restrict__ xent) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int LD = ((C + 3) & ~3) + 4;  // row stride: a multiple of 4 floats, consecutive rows 4 banks apart
+  float *e0 = sm, *e1 = e0 + N * LD, *A = e1 + N * LD;  // e1[a][k] = e[a][k + 1]; A[c][a]
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float *src = ehat + (long)i * N * C;
+  for (int it = tid; it < N * LD; it += XENT_NT) {
+    const int r = it / LD, k = it - r * LD;
+    e0[it] = k < C - 1 ? src[r * C + k] : 0.f;       // channels 0 .. C-2, zero beyond
+    e1[it] = k < C - 1 ? src[r * C + k + 1] : 0.f;   // channels 1 .. C-1
+  }
+  __syncthreads();
+  const int K4 = (C - 1 + 3) >> 2;
+  for (int p = tid; p < N * N; p += XENT_NT) {
+    const int c = p / N, a = p - c * N;
+    const float4 *x = reinterpret_cast<const float4 *>(e0 + c * LD), *y = reinterpret_cast<const float4 *>(e1 + a * LD);
+    float d = 0.f;
+    for (int k = 0; k < K4; ++k) {
+      const float4 u = x[k], v = y[k];
+      d += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+    A[c * N + a] = d / 0.1f;
+  }
+  __syncthreads();
+  for (int a = tid; a < N; a += XENT_NT) {
+    float m = -INFINITY;
+    for (int c = 0; c < N; ++c) m = fmaxf(m, A[c * N + a]);
+    float sum = 0.f;
+    for (int c = 0; c < N; ++c) sum += expf(A[c * N + a] - m);
+    xent[(long)a * (T - 1) + i] = (logf(sum) + m) - A[a * N + a];
+  }
+}
+
 }  // namespace
 }  // namespace crw
 
@@ -537,6 +575,11 @@ int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, in
 int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream) {
   crw::clear_stale_error();
   if (!ehat || !xent || T < 2 || N < 1 || C < 2 || (size_t)N * 4 > 60 * 1024) return CRW_EINVAL;
+  const size_t ld = (((size_t)C + 3) & ~(size_t)3) + 4, frame_lds = (2 * (size_t)N * ld + (size_t)N * N) * 4;
+  if (frame_lds <= 64 * 1024) {  // a frame's features fit LDS twice: a workgroup per frame
+    hipLaunchKernelGGL(xent_metric_frame_kernel, dim3(T - 1), dim3(XENT_NT), frame_lds, (hipStream_t)stream, ehat, T, N, C, xent);
+    return check_launch();
+  }
   hipLaunchKernelGGL(xent_metric_kernel, dim3(N, T - 1), dim3(64), (size_t)N * 4, (hipStream_t)stream, ehat, T, N, C,
                      xent);
   return check_launch();

@@ -894,6 +894,17 @@ def test_labelprop_topk_on_matrix_cores_agrees_with_vector_kernel(hip, T, N, C, 
     torch.testing.assert_close(ws, torch.ones_like(ws), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("T,N,C", [(256, 48, 128), (5, 3, 6), (9, 70, 33), (4, 130, 128)])  # the last: a frame too large for LDS twice
+def test_xent_metric_matches_oracle(hip, T, N, C):
+    """The 'horizontality' metric (src/utils.py:117-125; quirk Q8: channel-shifted features) at BASELINE config 5's shape and at
+    shapes that take the workgroup-per-frame kernel's edges (C - 1 not a multiple of 4) and the one-wave-per-pair fallback."""
+    g = torch.Generator().manual_seed(T * N + C)
+    emb = (torch.randn(1, N, C, generator=g) + 0.5 * torch.randn(T, N, C, generator=g)).float()
+    ref = orc.xent_metric(emb.numpy().astype(np.float64), np.float64)
+    got = hip.xent_metric(hip.normalize(emb.cuda())).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
 def test_labelprop_matches_oracle_mcords_shape(hip):
     """BASELINE config 5 shape [T,N] = [256,48] with truncation (CXT_SIZE=80)."""
     from imported.labelprop import LabelPropVOS_CRW

@@ -33,6 +33,8 @@ VARIANTS = [
     # default release + acquire fence (csrc/resnet_bn.hip rn_sums_tail_kernel)
     ("CRW_RN_TICKET", "relaxed", RESNET, "native_and_stepwise or training_step or reproducible"),
     ("CRW_RN_TICKET", "acqrel", RESNET, "native_and_stepwise or reproducible"),
+    # label-propagation top-k on the vector kernel where the default scores on the fp32 matrix cores (csrc/labelprop.hip)
+    ("CRW_LABELPROP_TOPK_VALU", "1", PARITY, "labelprop_matches_oracle_mcords_shape or labelprop_edge_cases or propagate_matches_reference"),
 ]
 
 
