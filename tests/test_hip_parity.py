@@ -892,6 +892,14 @@ def test_labelprop_topk_on_matrix_cores_agrees_with_vector_kernel(hip, T, N, C, 
     assert (Wm[:, :-1] >= Wm[:, 1:] - 1e-7).all()
     ws = Wm.sum(1)
     torch.testing.assert_close(ws, torch.ones_like(ws), rtol=1e-5, atol=1e-5)
+    # exact ties: every odd frame repeats the frame before it, so each key has a twin with the SAME score bit for bit inside either
+    # kernel -- the rule (highest value, then lowest candidate index) must then pick the same twin in both
+    feats2 = feats.clone()
+    feats2[1::2] = feats2[0:T - 1:2][: feats2[1::2].shape[0]]
+    Wm2, Im2 = hip.labelprop_topk(feats2, cxt, radius, 0.1, knn, first_frame=first, grid_w=1)
+    Wv2, Iv2 = hip.labelprop_topk(feats2, cxt, radius, 0.1, knn, first_frame=first, grid_w=N)
+    torch.testing.assert_close(Wm2, Wv2, rtol=2e-5, atol=1e-6)
+    assert (Im2 != Iv2).float().mean().item() < 2e-3
 
 
 @pytest.mark.parametrize("T,N,C", [(256, 48, 128), (5, 3, 6), (9, 70, 33), (4, 130, 128)])  # the last: a frame too large for LDS twice
