@@ -47,43 +47,63 @@ def rbf_gram(signal, gamma=None):
 
 
 def pelt_rbf(signal, pen, min_size=2, jump=5, gamma=None):
-    """-> sorted breakpoints (segment ends, the last one is len(signal))."""
+    """-> sorted breakpoints (segment ends, the last one is len(signal)).
+
+    Every admissible change position and every end point is a multiple of `jump` (or n), so the segment costs are evaluated on that
+    grid only: block sums from 2-D prefix sums S[i, j] = sum of gram[:i, :j] taken at the grid rows / columns (row by row the same
+    sequential additions as a full cumulative sum), the cost matrix of all (start, end) grid pairs in a handful of array
+    expressions, and the dynamic programme itself on plain floats -- the host runs this while the GPU propagates labels, and at
+    BASELINE config 5 it was the tail of the step."""
     n = len(signal)
     gram = rbf_gram(signal, gamma)
-    # prefix sums: S[i, j] = sum of gram[:i, :j]  ->  block sums in O(1)
-    S = np.zeros((n + 1, n + 1))
-    np.cumsum(np.cumsum(gram, axis=0), axis=1, out=S[1:, 1:])
-    diag = np.concatenate([[0.0], np.cumsum(np.diagonal(gram))])
-
-    def cost(a, b):
-        block = S[b, b] - S[a, b] - S[b, a] + S[a, a]
-        return (diag[b] - diag[a]) - block / (b - a)
-
-    # total[t] = penalised cost of the best segmentation of signal[:t], prev[t] = its last change position (-1: none yet).  The
-    # admissible last-change positions of one end point are costed in ONE vectorised expression (same arithmetic per element as
-    # cost() above; np.argmin takes the first minimum, as min() over the list did)
-    total = np.full(n + 1, np.inf)
-    prev = np.full(n + 1, -1, dtype=np.int64)
-    total[0] = 0.0
-    Sd = np.diagonal(S)
-    admissible = np.zeros(0, dtype=np.int64)
     ends = [k for k in range(0, n, jump) if k >= min_size] + [n]
+    grid = sorted(set(ends) | {v for v in (int(math.floor((b - min_size) / jump)) * jump for b in ends) if v >= 0} | {0})
+    pos = {v: i for i, v in enumerate(grid)}
+    g = np.asarray(grid)
+    m = len(grid)
+    # S on the grid: S[0, :] = S[:, 0] = 0; row i >= 1 of the full table is the running sum along the columns of c0[i - 1]
+    Sg = np.zeros((m, m))
+    if m > 1 and n > 0:
+        c0 = np.cumsum(gram, axis=0)
+        nz = g > 0
+        rows = np.cumsum(c0[g[nz] - 1], axis=1)
+        Sg[np.ix_(nz, nz)] = rows[:, g[nz] - 1]
+    dfull = np.concatenate([[0.0], np.cumsum(np.diagonal(gram))])
+    dg = dfull[g]
+    Sd = np.diagonal(Sg)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        # cost[a, b] of the segment [grid[a], grid[b]): (diag[b] - diag[a]) - (S[b,b] - S[a,b] - S[b,a] + S[a,a]) / (b - a)
+        block = Sd[None, :] - Sg - Sg.T + Sd[:, None]
+        cost = ((dg[None, :] - dg[:, None]) - block / (g[None, :] - g[:, None])).tolist()
+    # total[i] = penalised cost of the best segmentation of signal[:grid[i]], prev[i] = its last change position (grid index)
+    inf = float("inf")
+    total = [inf] * m
+    prev = [-1] * m
+    total[0] = 0.0
+    admissible = []
     for bkp in ends:
-        admissible = np.append(admissible, int(math.floor((bkp - min_size) / jump)) * jump)
-        t = admissible[np.isfinite(total[admissible]) & (bkp - admissible >= min_size)]
-        if t.size == 0:
+        b = pos[bkp]
+        start = int(math.floor((bkp - min_size) / jump)) * jump
+        if start >= 0:  # (a negative position is never the end of a segmentation)
+            admissible.append(pos[start])
+        best, best_t, cand = inf, -1, []
+        for t in admissible:
+            if total[t] == inf or bkp - grid[t] < min_size:
+                continue
+            c = total[t] + cost[t][b] + pen
+            cand.append((c, t))
+            if c < best:  # the first minimum, as min() over the candidates in order
+                best, best_t = c, t
+        if not cand:
             continue
-        block = S[bkp, bkp] - S[t, bkp] - S[bkp, t] + Sd[t]
-        cand = total[t] + ((diag[bkp] - diag[t]) - block / (bkp - t)) + pen
-        k = int(np.argmin(cand))
-        total[bkp] = cand[k]
-        prev[bkp] = t[k]
-        admissible = t[cand <= cand[k] + pen]  # PELT pruning
-    if not np.isfinite(total[n]):
+        total[b] = best
+        prev[b] = best_t
+        admissible = [t for c, t in cand if c <= best + pen]  # PELT pruning
+    if total[pos[n]] == inf:
         return [n]
     bkps = []
-    t = n
+    t = pos[n]
     while t > 0:
-        bkps.append(int(t))
-        t = int(prev[t])
+        bkps.append(grid[t])
+        t = prev[t]
     return sorted(bkps)
