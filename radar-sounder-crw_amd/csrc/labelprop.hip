@@ -342,6 +342,7 @@ __global__ __launch_bounds__(1024) void labelprop_gather_kernel(const float *__r
 // from L in global memory (written there by every frame as before; they are long since visible).  Same operations in the
 // same order: bit-identical results.
 constexpr int GATHER_NT = 256, GATHER_PF = 8;  // threads; prefetch registers per thread (knn * N <= 2048)
+constexpr int GATHER_CH = 20;                  // neighbours whose LDS reads are in flight together (KNN = 20: one batch per output; 4: 0.64, 10: 0.61, 20: 0.58 ms per cfg5 pass)
 __global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const float *__restrict__ seed,
                                                                          const float *__restrict__ W,
                                                                          const int32_t *__restrict__ I, int T, int N, int M,
@@ -391,19 +392,19 @@ __global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const f
     for (int it = tid; it < NM; it += GATHER_NT) {
       const int q = it / M, c = it % M;
       float p = 0.f;
-      // four neighbours at a time: their (index, weight) reads and then their label reads are independent LDS round trips
+      // GATHER_CH neighbours at a time: their (index, weight) reads and then their label reads are independent LDS round trips
       // (one neighbour after the other is two dependent round trips each: 3 of the 4 us a frame took); the sum stays in j order
-      for (int j0 = 0; j0 < knn; j0 += 4) {
-        int idx[4];
-        float w[4], v[4];
+      for (int j0 = 0; j0 < knn; j0 += GATHER_CH) {
+        int idx[GATHER_CH];
+        float w[GATHER_CH], v[GATHER_CH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GATHER_CH; ++u) {
           const int jj = min(j0 + u, knn - 1);
           idx[u] = in[jj * N + q];
           w[u] = wn[jj * N + q];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GATHER_CH; ++u) {
           // frame 0 sits in l0 = sm[0, NM), the ring behind it; a label older than the ring comes from global memory
           int off = idx[u] * M + c - epoch_base;
           if (off >= RNM) off -= RNM;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const f
           if (old) v[u] = ld_l2(L + (long)idx[u] * M + c);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GATHER_CH; ++u)
           if (j0 + u < knn) p += v[u] * w[u];
       }
       st_l2(L + ((long)n * N + q) * M + c, p);
