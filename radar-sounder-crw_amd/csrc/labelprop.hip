@@ -166,11 +166,10 @@ __global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float 
 #pragma unroll
     for (int j = 0; j < CSTEPS; ++j) b[j] = *reinterpret_cast<const float4 *>(kp + 16 * j);
   };
-  // NB operand buffers in rotation: the rows of the next NB - 1 items of this wave are in flight while one is multiplied (an item is
-  // 32 MFMAs = 0.5 us at 128 channels, an L2 round trip two to three times that)
-  constexpr int NB = CSTEPS <= 8 ? 4 : 2;  // (256 channels: two buffers are what the registers hold)
-  float4 bq[NB][CSTEPS];
-  auto score = [&](int item, const float4 (&b)[CSTEPS]) {
+  float4 b[CSTEPS], bn[CSTEPS];
+  if (wave < nitems) fetch(wave, b);
+  for (int item = wave; item < nitems; item += TK_NW) {
+    if (item + TK_NW < nitems) fetch(item + TK_NW, bn);
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd steps: two independent chains
 #pragma unroll
     for (int j = 0; j < CSTEPS; ++j) {
@@ -185,18 +184,8 @@ __global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float 
       const int rr = m - lo_r[r];
       if (m < N && rr >= 0 && rr < bw_r[r]) val[(4 * g + r) * maxcand + p * bw_r[r] + rr] = (acc0[r] + acc1[r]) / temp;
     }
-  };
 #pragma unroll
-  for (int k = 0; k < NB - 1; ++k)
-    if (wave + k * TK_NW < nitems) fetch(wave + k * TK_NW, bq[k]);
-  for (int base = wave; base < nitems; base += NB * TK_NW) {
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {  // item base + k * TK_NW sits in buffer k; the buffer freed by the previous item takes the item NB - 1 ahead
-      const int item = base + k * TK_NW;
-      if (item >= nitems) break;
-      if (item + (NB - 1) * TK_NW < nitems) fetch(item + (NB - 1) * TK_NW, bq[(k + NB - 1) % NB]);
-      score(item, bq[k]);
-    }
+    for (int j = 0; j < CSTEPS; ++j) b[j] = bn[j];
   }
   __syncthreads();
 
