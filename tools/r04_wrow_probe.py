@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stand-alone timing of the 64-channel block's weight gradient at the bench batch (P = 16128, 5 x 5 x 64 -> 64) through crw_rn_wgrad,
-alone on the chip.  CRW_RN_WROW=0|1 selects the kernel (read once per process); run under rocprofv3 --kernel-trace --stats for the
-kernel durations.  usage: python tools/r04_wrow_probe.py [P] [H] [W]"""
+alone on the chip -- the harness of the second experiment in profiles/r04_rn_row_experiment.log; run under rocprofv3 --kernel-trace
+--stats for the kernel durations.  usage: python tools/r04_wrow_probe.py [P] [H] [W]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "radar-sounder-crw_amd"))
 import torch
@@ -25,4 +25,4 @@ for _ in range(50):
     H.rn_wgrad(H.RN_FWD, P, (Hm, Wm, 64), (Hm, Wm, 64), (3, 3), 1, 1, xp, dp)
 e1.record()
 torch.cuda.synchronize()
-print(f"CRW_RN_WROW={os.environ.get('CRW_RN_WROW', '1')} P={P} {Hm}x{Wm}: {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us per call (kernel + slab sum + host gaps)", flush=True)
+print(f"P={P} {Hm}x{Wm}: {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us per call (kernel + slab sum + host gaps)", flush=True)
