@@ -485,8 +485,10 @@ def bench_labelprop(args):
         if args.model == 0:
             enc.eval()
 
+    lp = LabelPropVOS_CRW(cfg)  # once per run, like the reference's scripts (scripts/test/test_all.py:69, test_mc1.py:83)
+
     def run():
-        return crw_utils.propagate(seq, seg, enc, LabelPropVOS_CRW(cfg), M, False, False)
+        return crw_utils.propagate(seq, seg, enc, lp, M, False, False)
 
     for _ in range(max(1, args.warmup)):
         pred, xent, _ = run()

@@ -22,6 +22,8 @@ sizes: the stem on the gathered products instead of the patch-per-wave kernels, 
 and the mirror image backwards (crw_rn_bn_bwd, crw_rn_conv mode 1, crw_rn_wgrad, crw_rn_pool_bwd, crw_rn_stem16_wgrad,
 crw_rn_stem16_bwd).  No PyTorch / MIOpen convolution or batch-norm call is made on this path.
 """
+import weakref
+
 import torch
 
 import crw_hip as H
@@ -50,7 +52,7 @@ def supported(x, net):
     hl, wl = final_map(*x.shape[-2:])
     if hl * wl > 64 or _out(x.shape[-2] + 2, 7, 2, 3) * _out(x.shape[-1] + 2, 7, 2, 3) > 4096:
         return False
-    bns = _bn_modules(net)
+    bns = _bn_modules(net, fresh=True)
     if len(bns) != H.RN_NBN or any(m.training != net.training or m.eps != net.bn0.eps or m.momentum != net.bn0.momentum
                                    or not m.track_running_stats or not m.affine for m in bns):
         return False
@@ -78,8 +80,20 @@ class _Block:
         self.hout, self.wout = _out(hin, 3, self.stride, 1), _out(win, 3, self.stride, 1)
 
 
-def _bn_modules(net):
-    return [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+_BN_MEMO = [None, None]  # (weak reference to net, its BatchNorm modules) of the latest supported() call
+
+
+def _bn_modules(net, fresh=False):
+    """the 13 BatchNorm modules in module order.  supported() walks the module tree (fresh=True) and leaves the list for the forward
+    that follows it in the same call of Resnet.forward -- the walk is 0.07 ms of host time, twice per step without this"""
+    if not fresh and _BN_MEMO[0] is not None and _BN_MEMO[0]() is net:
+        bns = _BN_MEMO[1]
+        _BN_MEMO[0] = _BN_MEMO[1] = None
+        return bns
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    if fresh:
+        _BN_MEMO[0], _BN_MEMO[1] = weakref.ref(net), bns
+    return bns
 
 
 class HipResnetNative(torch.autograd.Function):
