@@ -14,6 +14,7 @@
  *   crw_labelprop_topk ...... einsum + mask + /temp + truncation + topk +
  *                             softmax                                         src/imported/maskedatt.py:151-175
  *   crw_labelprop_gather .... weighted label sum + argmax, frame by frame     src/imported/labelprop.py:106-114, src/utils.py:152-160
+ *   crw_labelprop_propagate . the same, chained prefix + parallel tail          (same lines; context bound of maskedatt.py:165-166)
  *   crw_xent_metric ......... "horizontality" metric                          src/utils.py:117-125
  *
  * Conventions
@@ -41,7 +42,7 @@ extern "C" {
 /* Bumps when a signature changes or an entry point is added.  The ONE place the number is written: crw_abi_version() returns
  * it, the ctypes binding (crw_hip.ABI_VERSION) parses it from this header, and __graft_entry__.build() / the host tests compare
  * the two. */
-#define CRW_ABI_VERSION 6
+#define CRW_ABI_VERSION 7
 
 #define CRW_OK 0
 #define CRW_EINVAL 1     /* bad shape / null pointer / unsupported size            */
@@ -124,6 +125,14 @@ int crw_labelprop_topk_grid(const float *ehat, int T, int N, int C, int cxt_size
  * (columns >= first_frame written; column 0 = seed when seed is given). */
 int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn,
                          int first_frame, float *L, float *pred, crw_stream_t stream);
+/* The same result for lists that come from crw_labelprop_topk(_grid) with context size `cxt_size` (same first_frame): their
+ * indices address the truncated key list, i.e. frame n's are < min(n, cxt_size + 1) * N, and the reference applies them to the
+ * untruncated label list (src/imported/labelprop.py:103-107 with src/imported/maskedatt.py:165-166) -- so only frames
+ * first_frame .. cxt_size form a chain (one workgroup, all their labels in LDS) and every later frame reads frames 0 .. cxt_size
+ * alone (one workgroup per frame, all at once).  Bit-identical L and pred; indices outside the bound are clamped to rows before
+ * the frame's own, never out of range.  Falls back to crw_labelprop_gather where the chained frames' labels exceed the LDS. */
+int crw_labelprop_propagate(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn, int first_frame,
+                            int cxt_size, float *L, float *pred, crw_stream_t stream);
 
 /* ehat [T,N,C] -> xent [N,T-1]  (channel-shifted within-frame affinity / 0.1, CE vs identity) */
 int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "crw_labelprop_topk": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_topk_grid": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_labelprop_propagate": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
     "crw_linear128_wgrad_ws_bytes": (_c_sz, [_c_int]),
     "crw_linear128_wgrad": (_c_int, [_p, _p, _p, _c_int, _p, _c_sz, _p]),
@@ -269,12 +270,19 @@ def labelprop_topk(ehat, cxt_size, radius, temp, knn, first_frame=1, grid_w=1):
     return W, I
 
 
-def labelprop_gather(seed, W, I, T, N, M, first_frame=1, L=None, pred=None):
+def labelprop_gather(seed, W, I, T, N, M, first_frame=1, L=None, pred=None, cxt_size=None):
+    """cxt_size: the context size the lists were made with by `labelprop_topk` (same first_frame) -> crw_labelprop_propagate
+    (chained frames in one workgroup, the frames beyond the context bound all at once); None: any lists, one workgroup."""
     knn = W.shape[1]
     if L is None:
         L = torch.empty(T * N, M, device=W.device, dtype=torch.float32)
     if pred is None:
         pred = torch.zeros(N, T, device=W.device, dtype=torch.float32)
+    if cxt_size is not None:
+        _check(lib().crw_labelprop_propagate(_dev(seed, "seed") if seed is not None else None, _dev(W, "W"),
+                                             _dev(I, "I", torch.int32), T, N, M, knn, int(first_frame), int(cxt_size),
+                                             _dev(L, "L"), _dev(pred, "pred"), _stream()), "crw_labelprop_propagate")
+        return L, pred
     _check(lib().crw_labelprop_gather(_dev(seed, "seed") if seed is not None else None, _dev(W, "W"),
                                       _dev(I, "I", torch.int32), T, N, M, knn, int(first_frame), _dev(L, "L"),
                                       _dev(pred, "pred"), _stream()), "crw_labelprop_gather")

@@ -13,6 +13,7 @@
 // [frame 0, last cxt frames] but are applied to the untruncated label list.
 #include "crw_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace crw {
 namespace {
@@ -442,6 +443,217 @@ __global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const f
   }
 }
 
+// ---- propagation when the lists' context bound is known (crw_labelprop_propagate) -------------------------------------------------
+// Index quirk Q7 read the other way round: crw_labelprop_topk's indices address the TRUNCATED key list [frame 0, last cxt frames],
+// i.e. they are < min(n, cxt + 1) * N, and the reference applies them to the UNTRUNCATED label list (src/imported/labelprop.py:
+// 103-107 with src/imported/maskedatt.py:165-166) -- so frame n reads the soft labels of frames 0 .. min(n - 1, cxt) and nothing
+// else.  Only the first cxt frames form a chain (frame n needs frame n - 1); every frame n > cxt depends on frames 0 .. cxt alone.
+//   prefix kernel: ONE workgroup walks frames first_frame .. cxt with ALL their labels in LDS (direct addressing, no ring).  Roles by
+//     wave: compute waves own one output (query, class) per lane and do nothing but the dependent chain -- label reads (addresses
+//     and weights already in registers), the sum in neighbour order, the LDS + global store, then the NEXT frame's (index, weight)
+//     reads from an LDS copy while the barrier gathers; service waves keep PX_D frames of lists in flight from global memory in
+//     rotating register sets, copy them into a double-buffered LDS slot two frames ahead, and take the arg-max / pred store of the
+//     previous frame.  The per-frame barrier waits for LDS traffic only (lds_barrier): global loads and stores stay in flight
+//     across frames, where labelprop_gather_lds_kernel's __syncthreads() drained them every frame (2.4 us per frame at cfg5).
+//   tail kernel: a workgroup per frame n > cxt, all at once, labels gathered from L in global memory (complete since the prefix).
+// Same operations in the same order per output as the kernels above: bit-identical L and pred.
+constexpr int PX_PF = 8, PX_D = 4, PX_NT = 512;  // list entries per service lane and frame; frames of lists in flight; threads at most
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N, class F>
+__device__ inline void static_for_px(F &&f) {  // f(integral_constant<0>) ... f(integral_constant<N - 1>): static register-set indices
+  if constexpr (N > 0) {
+    static_for_px<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int KP>
+__global__ __launch_bounds__(PX_NT) void labelprop_prefix_kernel(const float *__restrict__ seed, const float *__restrict__ W,
+                                                                   const int32_t *__restrict__ I, int T, int N, int M, int knn,
+                                                                   int first_frame, int last_frame, float *L,
+                                                                   float *__restrict__ pred, int ncw) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, NM = N * M, KN = knn * N;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool compute = wave < ncw;                          // wave-uniform role
+  const int NC = ncw * 64, NS = (int)blockDim.x - NC, st = tid - NC;
+  float *lab = sm;                                          // [(last_frame + 1) * NM] soft labels, frame-major like L
+  // [2][KN] (index, weight bits) pairs of frames f, f + 1 (slot = frame & 1), 8-byte aligned: one ds_read_b64 per neighbour
+  int2 *pl = reinterpret_cast<int2 *>(lab + (((long)(last_frame + 1) * NM + 1) & ~1L));
+
+  // labels of the frames before first_frame: frame 0 from the seed when given, the rest from L (filled by the caller)
+  for (int it = tid; it < first_frame * NM; it += (int)blockDim.x) {
+    float v;
+    if (seed && it < NM) {
+      v = seed[it / M] == (float)(it % M) ? 1.f : 0.f;
+      L[it] = v;
+    } else {
+      v = L[it];
+    }
+    lab[it] = v;
+  }
+  if (seed)
+    for (int q = tid; q < N; q += (int)blockDim.x) pred[(long)q * T] = seed[q];
+
+  auto list_at = [&](int f) { return (long)(min(f, last_frame) - first_frame) * KN; };  // clamped: loads are unconditional
+  float pw[PX_D][PX_PF];
+  int pi[PX_D][PX_PF];
+  auto svc_load = [&](int f, float (&w)[PX_PF], int (&ix)[PX_PF]) {
+    const long o = list_at(f);
+#pragma unroll
+    for (int u = 0; u < PX_PF; ++u) {
+      const int e = min(st + u * NS, KN - 1);
+      w[u] = W[o + e];
+      ix[u] = I[o + e];
+    }
+  };
+  auto svc_store = [&](int f, const float (&w)[PX_PF], const int (&ix)[PX_PF]) {
+#pragma unroll
+    for (int u = 0; u < PX_PF; ++u) {
+      const int e = st + u * NS;
+      if (e < KN) pl[(f & 1) * KN + e] = int2{ix[u], __float_as_int(w[u])};
+    }
+  };
+  if (!compute) {  // lists of the first two frames -> LDS; the next PX_D frames' lists into the register sets
+    svc_load(first_frame, pw[0], pi[0]);
+    svc_load(first_frame + 1, pw[1], pi[1]);
+    svc_store(first_frame, pw[0], pi[0]);
+    svc_store(first_frame + 1, pw[1], pi[1]);
+    static_for_px<PX_D>([&](auto U) {
+      constexpr int u = decltype(U)::value;
+      svc_load(first_frame + 2 + u, pw[u], pi[u]);
+    });
+  }
+  lds_barrier();
+
+  // compute lane: output `tid` = (q, c); LDS offsets and weights of its neighbours for the coming frame in registers
+  const int it = tid, q = min(it, NM - 1) / M, c = min(it, NM - 1) % M;
+  int a[KP];
+  float w[KP];
+  auto fetch_lists = [&](int f, int (&ix)[KP], float (&ww)[KP]) {  // frame f's lists: LDS -> registers (no dependence on labels)
+    const int2 *ln = pl + (f & 1) * KN;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      const int2 e = ln[min(j, knn - 1) * N + q];
+      ix[j] = e.x;
+      ww[j] = __int_as_float(e.y);
+    }
+  };
+  auto to_offsets = [&](int f, int (&ix)[KP], float (&ww)[KP]) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      ix[j] = min(max(ix[j], 0), f * N - 1) * M + c;  // in range whatever the lists hold (topk: < min(f, cxt + 1) * N)
+      if (j >= knn) ww[j] = 0.f;                      // padding slot: p + v * 0 = p
+    }
+  };
+  if (compute) {
+    fetch_lists(first_frame, a, w);
+    to_offsets(first_frame, a, w);
+  }
+
+  for (int fb = first_frame; fb <= last_frame; fb += PX_D) {
+    static_for_px<PX_D>([&](auto U) {
+      constexpr int u = decltype(U)::value;
+      const int f = fb + u;
+      if (f <= last_frame) {  // block-uniform
+        if (compute) {
+          float v[KP];
+#pragma unroll
+          for (int j = 0; j < KP; ++j) v[j] = lab[a[j]];
+          int na[KP];
+          float nw[KP];
+          fetch_lists(f + 1, na, nw);  // slot (f + 1) & 1: written before the previous barrier (garbage past last_frame: unused)
+          float p = 0.f;
+#pragma unroll
+          for (int j = 0; j < KP; ++j) p += v[j] * w[j];
+          if (it < NM) {
+            lab[(long)f * NM + it] = p;
+            L[(long)f * NM + it] = p;
+          }
+          to_offsets(f + 1, na, nw);
+#pragma unroll
+          for (int j = 0; j < KP; ++j) {
+            a[j] = na[j];
+            w[j] = nw[j];
+          }
+        } else {
+          if (f > first_frame) {  // arg-max of the previous frame (first maximum wins, like torch.argmax on distinct values)
+            for (int qq = st; qq < N; qq += NS) {
+              const float *row = lab + ((long)(f - 1) * N + qq) * M;
+              float bv = row[0];
+              int bi = 0;
+              for (int cc = 1; cc < M; ++cc) {
+                const float x = row[cc];
+                if (x > bv) { bv = x; bi = cc; }
+              }
+              pred[(long)qq * T + f - 1] = (float)bi;
+            }
+          }
+          svc_store(f + 2, pw[u], pi[u]);          // slot f & 1: last read (frame f's lists) before the previous barrier
+          svc_load(f + 2 + PX_D, pw[u], pi[u]);
+        }
+        lds_barrier();
+      }
+    });
+  }
+  if (!compute) {
+    for (int qq = st; qq < N; qq += NS) {
+      const float *row = lab + ((long)last_frame * N + qq) * M;
+      float bv = row[0];
+      int bi = 0;
+      for (int cc = 1; cc < M; ++cc) {
+        const float x = row[cc];
+        if (x > bv) { bv = x; bi = cc; }
+      }
+      pred[(long)qq * T + last_frame] = (float)bi;
+    }
+  }
+}
+
+// frames t0 .. T-1, none of which reads a label this launch writes: a workgroup per frame, neighbours' labels from L (global memory)
+constexpr int TAIL_NT = 256, TAIL_CH = 16;
+__global__ __launch_bounds__(TAIL_NT) void labelprop_tail_kernel(const float *__restrict__ W, const int32_t *__restrict__ I, int T, int N,
+                                                                 int M, int knn, int first_frame, int t0, float *L,
+                                                                 float *__restrict__ pred) {
+  extern __shared__ __attribute__((aligned(16))) float slot[];  // [N * M]
+  const int tid = threadIdx.x, NM = N * M, n = t0 + blockIdx.x;
+  const float *Wn = W + (long)(n - first_frame) * knn * N;
+  const int32_t *In = I + (long)(n - first_frame) * knn * N;
+  const int row_lim = n * N - 1;
+  for (int it = tid; it < NM; it += TAIL_NT) {
+    const int q = it / M, c = it % M;
+    float p = 0.f;
+    for (int j0 = 0; j0 < knn; j0 += TAIL_CH) {
+      int idx[TAIL_CH];
+      float w[TAIL_CH], v[TAIL_CH];
+#pragma unroll
+      for (int u = 0; u < TAIL_CH; ++u) {
+        const int jj = min(j0 + u, knn - 1);
+        idx[u] = min(max(In[jj * N + q], 0), row_lim);
+        w[u] = Wn[jj * N + q];
+      }
+#pragma unroll
+      for (int u = 0; u < TAIL_CH; ++u) v[u] = L[(long)idx[u] * M + c];
+#pragma unroll
+      for (int u = 0; u < TAIL_CH; ++u)
+        if (j0 + u < knn) p += v[u] * w[u];
+    }
+    L[((long)n * N + q) * M + c] = p;
+    slot[it] = p;
+  }
+  __syncthreads();
+  for (int q = tid; q < N; q += TAIL_NT) {
+    const float *row = slot + q * M;
+    float bv = row[0];
+    int bi = 0;
+    for (int c = 1; c < M; ++c) {
+      const float x = row[c];
+      if (x > bv) { bv = x; bi = c; }
+    }
+    pred[(long)q * T + n] = (float)bi;
+  }
+}
+
 // xent[a, i] = logsumexp_c A_i[c, a] - A_i[a, a],  A_i[c, a] = <ehat[i,c,0:C-1], ehat[i,a,1:C]> / 0.1
 __global__ __launch_bounds__(64) void xent_metric_kernel(const float *__restrict__ ehat, int T, int N, int C,
                                                          float *__restrict__ xent) {
@@ -571,6 +783,50 @@ int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, in
   hipLaunchKernelGGL(labelprop_gather_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seed, W, I, T, N, M, knn,
                      first_frame, L, pred);
   return check_launch();
+}
+
+int crw_labelprop_propagate(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn, int first_frame,
+                            int cxt_size, float *L, float *pred, crw_stream_t stream) {
+  crw::clear_stale_error();
+  if (!W || !I || !L || !pred || T < 2 || N < 1 || M < 1 || knn < 1 || first_frame < 1 || first_frame >= T || cxt_size < 1)
+    return CRW_EINVAL;
+  const long NM = (long)N * M, KN = (long)knn * N;
+  // frames from t0 on read no label of this call: one frame alone, or every frame beyond the context bound
+  const int t0 = (T - first_frame == 1) ? first_frame : (first_frame > cxt_size + 1 ? first_frame : (cxt_size + 1 < T ? cxt_size + 1 : T));
+  const int last = t0 - 1;  // the chained frames first_frame .. last (none when last < first_frame)
+  static const bool seq = getenv("CRW_LABELPROP_GATHER_SEQ") && getenv("CRW_LABELPROP_GATHER_SEQ")[0] == '1';  // A/B: one-workgroup walk
+  const int ncw = (int)((NM + 63) / 64), nsv = (int)((KN + 64 * PX_PF - 1) / (64 * PX_PF));
+  const size_t px_lds = (size_t)((((long)(last + 1) * NM + 1) & ~1L) * 4 + 16 * KN);
+  const bool px_ok = last < first_frame || (knn <= 24 && ncw + nsv <= PX_NT / 64 && px_lds <= 150 * 1024)  /* 32 neighbours in registers spill */;
+  if (seq || !px_ok || NM * 4 > 60 * 1024 || (long)T * N >= (1L << 30) / M)
+    return crw_labelprop_gather(seed, W, I, T, N, M, knn, first_frame, L, pred, stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (last >= first_frame) {
+    static bool attr[3] = {false, false, false};  // dynamic-LDS limit raised, per instantiation
+    auto launch = [&](auto kern, int which) -> int {
+      if (!attr[which]) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+          g_last_hip_error = (int)hipGetLastError();
+          return CRW_EHIP;
+        }
+        attr[which] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(1), dim3((ncw + nsv) * 64), px_lds, s, seed, W, I, T, N, M, knn, first_frame, last, L, pred, ncw);
+      return check_launch();
+    };
+    int rc;
+    if (knn <= 8) rc = launch(labelprop_prefix_kernel<8>, 0);
+    else if (knn <= 16) rc = launch(labelprop_prefix_kernel<16>, 1);
+    else rc = launch(labelprop_prefix_kernel<24>, 2);
+    if (rc != CRW_OK) return rc;
+  } else if (seed) {  // a seed with a later first frame and no chained frame: the general kernel initialises frame 0
+    return crw_labelprop_gather(seed, W, I, T, N, M, knn, first_frame, L, pred, stream);
+  }
+  if (t0 < T) {
+    hipLaunchKernelGGL(labelprop_tail_kernel, dim3(T - t0), dim3(TAIL_NT), (size_t)NM * 4, s, W, I, T, N, M, knn, first_frame, t0, L, pred);
+    return check_launch();
+  }
+  return CRW_OK;
 }
 
 int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream) {

@@ -64,7 +64,7 @@ class LabelPropVOS_CRW(object):
         L = torch.empty((n + 1) * N, M, device=E.device, dtype=torch.float32)
         L[:n * N] = torch.cat(list(masks), 0).flatten(2).permute(0, 2, 1).reshape(n * N, M)
         Wt, It = crw_hip.labelprop_topk(E, self.cxt_size, self.radius, self.temperature, self.topk, first_frame=n, grid_w=w)
-        crw_hip.labelprop_gather(None, Wt, It, n + 1, N, M, first_frame=n, L=L)
+        crw_hip.labelprop_gather(None, Wt, It, n + 1, N, M, first_frame=n, L=L, cxt_size=self.cxt_size)
         return L[n * N:].reshape(N, M).t().reshape(1, M, h, w)
 
     def propagate_all(self, feats, seed, nclasses, grid_w=1):
@@ -74,5 +74,5 @@ class LabelPropVOS_CRW(object):
         self._check_grid(N // grid_w, grid_w)
         self._band(N // grid_w, grid_w, feats.device)
         Wt, It = crw_hip.labelprop_topk(feats, self.cxt_size, self.radius, self.temperature, self.topk, first_frame=1, grid_w=grid_w)
-        L, pred = crw_hip.labelprop_gather(seed.float().contiguous(), Wt, It, T, N, nclasses, first_frame=1)
+        L, pred = crw_hip.labelprop_gather(seed.float().contiguous(), Wt, It, T, N, nclasses, first_frame=1, cxt_size=self.cxt_size)
         return pred, L

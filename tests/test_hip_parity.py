@@ -932,6 +932,51 @@ def test_labelprop_matches_oracle_mcords_shape(hip):
     assert mism == 0, f"{mism} of {ref.size} labels differ"
 
 
+@pytest.mark.parametrize("T,N,C,M,cxt,radius,knn,grid_w", [
+    (256, 48, 128, 4, 80, 10, 20, 1),   # BASELINE config 5: 80 chained frames in one workgroup + 175 frames at once
+    (14, 10, 16, 3, 3, 4, 5, 1),        # short chain, long tail
+    (9, 12, 16, 3, 20, 3, 4, 1),        # T <= cxt + 1: every frame chained, no tail
+    (40, 63, 64, 6, 7, 5, 10, 1),       # 378 outputs per frame: six compute waves
+    (30, 24, 32, 2, 1, 6, 24, 1),       # cxt = 1: frame 1 alone is chained; 24 neighbours (the widest register instance)
+    (12, 30, 16, 3, 4, 3, 7, 5),        # 6 x 5 node grid
+    (20, 120, 32, 5, 3, 4, 6, 1),       # 600 outputs per frame: beyond the compute waves -> the one-workgroup walk
+    (16, 40, 32, 3, 5, 40, 30, 1)])     # 30 neighbours: beyond the register instances -> the one-workgroup walk
+def test_labelprop_propagate_equals_the_one_workgroup_walk(hip, T, N, C, M, cxt, radius, knn, grid_w):
+    """crw_labelprop_propagate (chained frames first_frame..cxt in one workgroup with their labels in LDS, every later frame at once:
+    the truncated lists' indices are < min(n, cxt + 1) * N, src/imported/maskedatt.py:165-166 applied as in
+    src/imported/labelprop.py:103-107) against crw_labelprop_gather (one workgroup, frame after frame, any lists): soft labels and
+    label map bit for bit -- for the whole radargram, for a later first frame with the earlier labels given, and one frame at a time."""
+    g = torch.Generator().manual_seed(T * 7 + N)
+    feats = hip.normalize((torch.randn(1, N, C, generator=g) + 0.5 * torch.randn(T, N, C, generator=g)).float().cuda())
+    seed = (torch.arange(N) * M // N).float().cuda()
+    Wt, It = hip.labelprop_topk(feats, cxt, radius, 0.1, knn, first_frame=1, grid_w=grid_w)
+    for n in range(1, T):  # the bound the new entry point relies on
+        assert int(It[n - 1].max()) < min(n, cxt + 1) * N
+    L0, p0 = hip.labelprop_gather(seed, Wt, It, T, N, M, first_frame=1)
+    L1, p1 = hip.labelprop_gather(seed, Wt, It, T, N, M, first_frame=1, cxt_size=cxt)
+    assert torch.equal(L0, L1) and torch.equal(p0, p1)
+    for first in sorted({2, max(2, cxt), min(T - 1, cxt + 1), min(T - 1, cxt + 3), T - 1}):
+        if first >= T:
+            continue
+        Wf, If = hip.labelprop_topk(feats, cxt, radius, 0.1, knn, first_frame=first, grid_w=grid_w)
+        assert torch.equal(Wf, Wt[first - 1:]) and torch.equal(If, It[first - 1:])
+        La, Lb = L0.clone(), L0.clone()
+        La[first * N:] = -7.0
+        Lb[first * N:] = -7.0
+        pa, pb = torch.full((N, T), -1.0).cuda(), torch.full((N, T), -1.0).cuda()
+        hip.labelprop_gather(None, Wf, If, T, N, M, first_frame=first, L=La, pred=pa)
+        hip.labelprop_gather(None, Wf, If, T, N, M, first_frame=first, L=Lb, pred=pb, cxt_size=cxt)
+        assert torch.equal(La, L0) and torch.equal(Lb, L0), first
+        assert torch.equal(pa, pb) and torch.equal(pb[:, first:], p0[:, first:]) and (pb[:, :first] == -1).all(), first
+    # one frame per call (LabelPropVOS_CRW.predict)
+    Ls = L0.clone()
+    Ls[N:] = 0
+    for n in range(1, T):
+        Wn, In = hip.labelprop_topk(feats[:n + 1], cxt, radius, 0.1, knn, first_frame=n, grid_w=grid_w)
+        hip.labelprop_gather(None, Wn, In, n + 1, N, M, first_frame=n, L=Ls[:(n + 1) * N], cxt_size=cxt)
+    assert torch.equal(Ls, L0)
+
+
 def test_bidirectional_segmentation_pipeline_matches_oracle(hip):
     """forward pass + reversed pass (use_last) + class-2 merge over two radargram items, checked
     against the same pipeline restated with the CPU oracle (scripts/test/test_all.py:91-159)."""
