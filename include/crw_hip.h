@@ -134,6 +134,13 @@ int crw_labelprop_gather(const float *seed, const float *W, const int32_t *I, in
 int crw_labelprop_propagate(const float *seed, const float *W, const int32_t *I, int T, int N, int M, int knn, int first_frame,
                             int cxt_size, float *L, float *pred, crw_stream_t stream);
 
+/* HOST function (no GPU work, host pointers): the change-point search of `propagate` (src/utils.py:125-132,
+ * ruptures.Pelt(model="rbf").fit(signal).predict(pen)) -- PELT with the RBF kernel cost at ruptures' documented defaults
+ * min_size 2, jump 5; gamma <= 0: the median heuristic.  signal [n] doubles -> sorted breakpoints bkps[0..count) (segment ends, the
+ * last one is n); returns count >= 1, or a negative status.  The arithmetic of pelt.py in the same order (parity with ruptures
+ * itself is unpinned: it is not installed here). */
+int crw_pelt_rbf(const double *signal, int n, double pen, int min_size, int jump, double gamma, int *bkps, int max_bkps);
+
 /* ehat [T,N,C] -> xent [N,T-1]  (channel-shifted within-frame affinity / 0.1, CE vs identity) */
 int crw_xent_metric(const float *ehat, int T, int N, int C, float *xent, crw_stream_t stream);
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "crw_labelprop_topk": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_topk_grid": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_labelprop_gather": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "crw_pelt_rbf": (_c_int, [_p, _c_int, ctypes.c_double, _c_int, _c_int, ctypes.c_double, _p, _c_int]),
     "crw_labelprop_propagate": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "crw_xent_metric": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
     "crw_linear128_wgrad_ws_bytes": (_c_sz, [_c_int]),
@@ -287,6 +288,20 @@ def labelprop_gather(seed, W, I, T, N, M, first_frame=1, L=None, pred=None, cxt_
                                       _dev(I, "I", torch.int32), T, N, M, knn, int(first_frame), _dev(L, "L"),
                                       _dev(pred, "pred"), _stream()), "crw_labelprop_gather")
     return L, pred
+
+
+def pelt_rbf(signal, pen, min_size=2, jump=5, gamma=None):
+    """HOST function of the library (no GPU): PELT with the RBF kernel cost on a 1-D signal -> sorted breakpoints, the last one
+    len(signal) -- pelt.pelt_rbf's arithmetic in C++ (csrc/pelt.cpp)."""
+    import numpy as np
+    x = np.ascontiguousarray(np.asarray(signal, dtype=np.float64).reshape(-1))
+    n = len(x)
+    out = np.empty(max(n, 1) + 1, dtype=np.int32)
+    cnt = lib().crw_pelt_rbf(ctypes.c_void_p(x.ctypes.data), n, float(pen), int(min_size), int(jump),
+                             -1.0 if gamma is None else float(gamma), ctypes.c_void_p(out.ctypes.data), len(out))
+    if cnt < 1:
+        raise CrwError("crw_pelt_rbf", -cnt, 0)
+    return [int(v) for v in out[:cnt]]
 
 
 def xent_metric(ehat):

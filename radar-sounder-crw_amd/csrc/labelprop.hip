@@ -451,21 +451,14 @@ __global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const f
 //   prefix kernel: ONE workgroup walks frames first_frame .. cxt with ALL their labels in LDS (direct addressing, no ring).  Roles by
 //     wave: compute waves own one output (query, class) per lane and do nothing but the dependent chain -- label reads (addresses
 //     and weights already in registers), the sum in neighbour order, the LDS + global store, then the NEXT frame's (index, weight)
-//     reads from an LDS copy while the barrier gathers; service waves keep PX_D frames of lists in flight from global memory in
-//     rotating register sets, copy them into a double-buffered LDS slot two frames ahead, and take the arg-max / pred store of the
-//     previous frame.  The per-frame barrier waits for LDS traffic only (lds_barrier): global loads and stores stay in flight
+//     reads from an LDS copy while the barrier gathers; loader waves, one frame each in rotation, keep the lists of the next frames
+//     in flight from global memory and copy them into a double-buffered LDS slot two frames ahead; one more wave takes the
+//     arg-max / pred store of the previous frame.  The per-frame barrier waits for LDS traffic only (lds_barrier): global loads and stores stay in flight
 //     across frames, where labelprop_gather_lds_kernel's __syncthreads() drained them every frame (2.4 us per frame at cfg5).
 //   tail kernel: a workgroup per frame n > cxt, all at once, labels gathered from L in global memory (complete since the prefix).
 // Same operations in the same order per output as the kernels above: bit-identical L and pred.
-constexpr int PX_PF = 8, PX_D = 4, PX_NT = 512;  // list entries per service lane and frame; frames of lists in flight; threads at most
+constexpr int PX_PF = 16, PX_NT = 512;  // list entries per loader lane and frame (a frame's lists: knn * N <= 64 * PX_PF); threads at most
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int N, class F>
-__device__ inline void static_for_px(F &&f) {  // f(integral_constant<0>) ... f(integral_constant<N - 1>): static register-set indices
-  if constexpr (N > 0) {
-    static_for_px<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 
 template <int KP>
 __global__ __launch_bounds__(PX_NT) void labelprop_prefix_kernel(const float *__restrict__ seed, const float *__restrict__ W,
@@ -473,12 +466,20 @@ __global__ __launch_bounds__(PX_NT) void labelprop_prefix_kernel(const float *__
                                                                    int first_frame, int last_frame, float *L,
                                                                    float *__restrict__ pred, int ncw) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int tid = threadIdx.x, NM = N * M, KN = knn * N;
+  const int tid = threadIdx.x, lane = tid & 63, NM = N * M, KN = knn * N;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool compute = wave < ncw;                          // wave-uniform role
-  const int NC = ncw * 64, NS = (int)blockDim.x - NC, st = tid - NC;
+  // wave-uniform roles: compute waves [0, ncw), D list loaders [ncw, nwaves - 1), ONE arg-max wave (the last).
+  // Loader k owns the frames f with (f - first_frame) % D == k: in the phase of frame f it copies the lists of frame f + 2 from its
+  // registers into LDS and requests those of frame f + 2 + D -- a wave has ONE request in flight and touches it D phases later, so
+  // the s_waitcnt vmcnt(0) hipcc puts in front of the copy meets loads that are long back.  (Measured the other ways: the arg-max's
+  // pred stores in a loader wave -- two event types on one counter, hipcc waits for everything: 1.36 us per frame; several register
+  // sets in rotation in one wave -- hipcc's counted waits across the loop's back edge come out as vmcnt(0..14): the same.)
+  const int nwaves = (int)blockDim.x >> 6, D = nwaves - 1 - ncw;
+  const bool compute = wave < ncw, loader = !compute && wave < nwaves - 1, amax = wave == nwaves - 1;
+  const int lk = wave - ncw, at = tid - (nwaves - 1) * 64;
+  constexpr int KNP = 64 * PX_PF;                           // entries of a list slot in LDS
   float *lab = sm;                                          // [(last_frame + 1) * NM] soft labels, frame-major like L
-  // [2][KN] (index, weight bits) pairs of frames f, f + 1 (slot = frame & 1), 8-byte aligned: one ds_read_b64 per neighbour
+  // [2][KNP] (index, weight bits) pairs of frames f, f + 1 (slot = frame & 1), 8-byte aligned: one ds_read_b64 per neighbour
   int2 *pl = reinterpret_cast<int2 *>(lab + (((long)(last_frame + 1) * NM + 1) & ~1L));
 
   // labels of the frames before first_frame: frame 0 from the seed when given, the rest from L (filled by the caller)
@@ -495,43 +496,42 @@ __global__ __launch_bounds__(PX_NT) void labelprop_prefix_kernel(const float *__
   if (seed)
     for (int q = tid; q < N; q += (int)blockDim.x) pred[(long)q * T] = seed[q];
 
-  auto list_at = [&](int f) { return (long)(min(f, last_frame) - first_frame) * KN; };  // clamped: loads are unconditional
-  float pw[PX_D][PX_PF];
-  int pi[PX_D][PX_PF];
-  auto svc_load = [&](int f, float (&w)[PX_PF], int (&ix)[PX_PF]) {
-    const long o = list_at(f);
+  float pw[PX_PF];
+  int pi[PX_PF];
+  auto svc_load = [&](int f) {  // (clamped, unconditional: a frame past the last one re-reads the last one's lists, never used)
+    const long o = (long)(min(f, last_frame) - first_frame) * KN;
 #pragma unroll
     for (int u = 0; u < PX_PF; ++u) {
-      const int e = min(st + u * NS, KN - 1);
-      w[u] = W[o + e];
-      ix[u] = I[o + e];
+      const int e = min(lane + u * 64, KN - 1);
+      pw[u] = W[o + e];
+      pi[u] = I[o + e];
     }
   };
-  auto svc_store = [&](int f, const float (&w)[PX_PF], const int (&ix)[PX_PF]) {
+  auto svc_store = [&](int f) {  // unconditional too: a slot holds 64 * PX_PF >= KN entries, the surplus repeats the last entry
 #pragma unroll
-    for (int u = 0; u < PX_PF; ++u) {
-      const int e = st + u * NS;
-      if (e < KN) pl[(f & 1) * KN + e] = int2{ix[u], __float_as_int(w[u])};
-    }
+    for (int u = 0; u < PX_PF; ++u) pl[(f & 1) * KNP + lane + u * 64] = int2{pi[u], __float_as_int(pw[u])};
   };
-  if (!compute) {  // lists of the first two frames -> LDS; the next PX_D frames' lists into the register sets
-    svc_load(first_frame, pw[0], pi[0]);
-    svc_load(first_frame + 1, pw[1], pi[1]);
-    svc_store(first_frame, pw[0], pi[0]);
-    svc_store(first_frame + 1, pw[1], pi[1]);
-    static_for_px<PX_D>([&](auto U) {
-      constexpr int u = decltype(U)::value;
-      svc_load(first_frame + 2 + u, pw[u], pi[u]);
-    });
+  if (loader) {  // lists of the first two frames -> LDS; then every loader requests its first frame
+    if (lk == 0) {
+      svc_load(first_frame);
+      svc_store(first_frame);
+    }
+    if (lk == (D > 1 ? 1 : 0)) {
+      svc_load(first_frame + 1);
+      svc_store(first_frame + 1);
+    }
+    svc_load(first_frame + 2 + lk);
   }
   lds_barrier();
 
   // compute lane: output `tid` = (q, c); LDS offsets and weights of its neighbours for the coming frame in registers
-  const int it = tid, q = min(it, NM - 1) / M, c = min(it, NM - 1) % M;
+  // (the surplus lanes of the last compute wave repeat output NM - 1: same reads, same sum, same stores -- no branch around the
+  // chain: under `if (it < NM)` hipcc sinks the label reads into the branch and waits for them one by one, 24 LDS round trips)
+  const int it = min(tid, NM - 1), q = it / M, c = it % M;
   int a[KP];
   float w[KP];
   auto fetch_lists = [&](int f, int (&ix)[KP], float (&ww)[KP]) {  // frame f's lists: LDS -> registers (no dependence on labels)
-    const int2 *ln = pl + (f & 1) * KN;
+    const int2 *ln = pl + (f & 1) * KNP;
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
       const int2 e = ln[min(j, knn - 1) * N + q];
@@ -551,53 +551,48 @@ __global__ __launch_bounds__(PX_NT) void labelprop_prefix_kernel(const float *__
     to_offsets(first_frame, a, w);
   }
 
-  for (int fb = first_frame; fb <= last_frame; fb += PX_D) {
-    static_for_px<PX_D>([&](auto U) {
-      constexpr int u = decltype(U)::value;
-      const int f = fb + u;
-      if (f <= last_frame) {  // block-uniform
-        if (compute) {
-          float v[KP];
+  int turn = 0;  // (f - first_frame) % D
+  for (int f = first_frame; f <= last_frame; ++f) {
+    if (compute) {
+      float v[KP];
 #pragma unroll
-          for (int j = 0; j < KP; ++j) v[j] = lab[a[j]];
-          int na[KP];
-          float nw[KP];
-          fetch_lists(f + 1, na, nw);  // slot (f + 1) & 1: written before the previous barrier (garbage past last_frame: unused)
-          float p = 0.f;
+      for (int j = 0; j < KP; ++j) v[j] = lab[a[j]];
+      int na[KP];
+      float nw[KP];
+      fetch_lists(f + 1, na, nw);  // slot (f + 1) & 1: written before the previous barrier (past last_frame: unused)
+      float p = 0.f;
 #pragma unroll
-          for (int j = 0; j < KP; ++j) p += v[j] * w[j];
-          if (it < NM) {
-            lab[(long)f * NM + it] = p;
-            L[(long)f * NM + it] = p;
-          }
-          to_offsets(f + 1, na, nw);
+      for (int j = 0; j < KP; ++j) p += v[j] * w[j];
+      lab[(long)f * NM + it] = p;
+      L[(long)f * NM + it] = p;
+      to_offsets(f + 1, na, nw);
 #pragma unroll
-          for (int j = 0; j < KP; ++j) {
-            a[j] = na[j];
-            w[j] = nw[j];
-          }
-        } else {
-          if (f > first_frame) {  // arg-max of the previous frame (first maximum wins, like torch.argmax on distinct values)
-            for (int qq = st; qq < N; qq += NS) {
-              const float *row = lab + ((long)(f - 1) * N + qq) * M;
-              float bv = row[0];
-              int bi = 0;
-              for (int cc = 1; cc < M; ++cc) {
-                const float x = row[cc];
-                if (x > bv) { bv = x; bi = cc; }
-              }
-              pred[(long)qq * T + f - 1] = (float)bi;
-            }
-          }
-          svc_store(f + 2, pw[u], pi[u]);          // slot f & 1: last read (frame f's lists) before the previous barrier
-          svc_load(f + 2 + PX_D, pw[u], pi[u]);
-        }
-        lds_barrier();
+      for (int j = 0; j < KP; ++j) {
+        a[j] = na[j];
+        w[j] = nw[j];
       }
-    });
+    } else if (loader) {
+      if (turn == lk) {
+        svc_store(f + 2);  // slot f & 1: last read (frame f's lists) before the previous barrier
+        svc_load(f + 2 + D);
+      }
+    } else if (f > first_frame) {  // arg-max of the previous frame (first maximum wins, like torch.argmax on distinct values)
+      for (int qq = at; qq < N; qq += 64) {
+        const float *row = lab + ((long)(f - 1) * N + qq) * M;
+        float bv = row[0];
+        int bi = 0;
+        for (int cc = 1; cc < M; ++cc) {
+          const float x = row[cc];
+          if (x > bv) { bv = x; bi = cc; }
+        }
+        pred[(long)qq * T + f - 1] = (float)bi;
+      }
+    }
+    turn = turn + 1 == D ? 0 : turn + 1;
+    lds_barrier();
   }
-  if (!compute) {
-    for (int qq = st; qq < N; qq += NS) {
+  if (amax) {
+    for (int qq = at; qq < N; qq += 64) {
       const float *row = lab + ((long)last_frame * N + qq) * M;
       float bv = row[0];
       int bi = 0;
@@ -795,9 +790,11 @@ int crw_labelprop_propagate(const float *seed, const float *W, const int32_t *I,
   const int t0 = (T - first_frame == 1) ? first_frame : (first_frame > cxt_size + 1 ? first_frame : (cxt_size + 1 < T ? cxt_size + 1 : T));
   const int last = t0 - 1;  // the chained frames first_frame .. last (none when last < first_frame)
   static const bool seq = getenv("CRW_LABELPROP_GATHER_SEQ") && getenv("CRW_LABELPROP_GATHER_SEQ")[0] == '1';  // A/B: one-workgroup walk
-  const int ncw = (int)((NM + 63) / 64), nsv = (int)((KN + 64 * PX_PF - 1) / (64 * PX_PF));
-  const size_t px_lds = (size_t)((((long)(last + 1) * NM + 1) & ~1L) * 4 + 16 * KN);
-  const bool px_ok = last < first_frame || (knn <= 24 && ncw + nsv <= PX_NT / 64 && px_lds <= 150 * 1024)  /* 32 neighbours in registers spill */;
+  // chained frames: compute waves + 1..4 list loaders (fewer when the outputs need more compute waves) + the arg-max wave
+  const int ncw = (int)((NM + 63) / 64), nld = PX_NT / 64 - 1 - ncw < 4 ? PX_NT / 64 - 1 - ncw : 4;
+  const size_t px_lds = (size_t)((((long)(last + 1) * NM + 1) & ~1L) * 4 + 16L * 64 * PX_PF);
+  const bool px_ok = last < first_frame || (knn <= 24 /* 32 neighbours in registers spill */ && nld >= 1 && KN <= 64 * PX_PF &&
+                                            px_lds <= 150 * 1024);
   if (seq || !px_ok || NM * 4 > 60 * 1024 || (long)T * N >= (1L << 30) / M)
     return crw_labelprop_gather(seed, W, I, T, N, M, knn, first_frame, L, pred, stream);
   hipStream_t s = (hipStream_t)stream;
@@ -811,7 +808,7 @@ int crw_labelprop_propagate(const float *seed, const float *W, const int32_t *I,
         }
         attr[which] = true;
       }
-      hipLaunchKernelGGL(kern, dim3(1), dim3((ncw + nsv) * 64), px_lds, s, seed, W, I, T, N, M, knn, first_frame, last, L, pred, ncw);
+      hipLaunchKernelGGL(kern, dim3(1), dim3((ncw + nld + 1) * 64), px_lds, s, seed, W, I, T, N, M, knn, first_frame, last, L, pred, ncw);
       return check_launch();
     };
     int rc;

@@ -87,7 +87,8 @@ def change_point(xent, diffs=None):
     """PELT(rbf, pen=5) on the column-to-column change of the metric, then `result[-2] + 5` clamped at 0
     (src/utils.py:125-132).  Uses `ruptures` when it is importable, else the restatement of its published
     algorithm in pelt.py (parity unpinned, see there); like the reference, any failure -- e.g. fewer than
-    two breakpoints -- yields None.  diffs: the (host, event) pair of `column_diffs_async` if already requested."""
+    two breakpoints -- yields None.  (`crw_hip.pelt_rbf` is pelt.py's arithmetic as a host function of the library: the numpy
+    form took 0.9 ms per radargram and had become the tail of the config-5 step.)  diffs: the (host, event) pair of `column_diffs_async` if already requested."""
     if diffs is not None:
         diffs[1].synchronize()
         diffs = diffs[0].numpy()
@@ -97,9 +98,8 @@ def change_point(xent, diffs=None):
         try:
             import ruptures as rpt
             result = rpt.Pelt(model="rbf").fit(diffs).predict(pen=5)
-        except ImportError:
-            from pelt import pelt_rbf
-            result = pelt_rbf(diffs, pen=5)
+        except ImportError:  # pelt.py's restatement, as the library's host function (csrc/pelt.cpp: same sums, plain C++)
+            result = crw_hip.pelt_rbf(diffs, pen=5)
         return max(0, int(result[-2] + 5))
     except Exception:
         return None

@@ -198,6 +198,33 @@ def test_pelt_rbf_restatement():
     assert crw_utils.change_point(torch.zeros(4, 30)) is None
 
 
+def test_native_pelt_equals_the_numpy_restatement():
+    """`crw_pelt_rbf` (csrc/pelt.cpp, a HOST function of the library: what `utils.change_point` calls) repeats pelt.py's sums in
+    pelt.py's order: the same breakpoints on random, shifted and tie-ridden signals of every length the dataset can produce,
+    with the median heuristic and with a given bandwidth; degenerate inputs behave alike."""
+    import pelt
+    import crw_hip
+    rng = np.random.default_rng(3)
+    for trial in range(600):
+        n = int(rng.integers(3, 300))
+        kind = trial % 4
+        if kind == 0:
+            x = rng.random(n)
+        elif kind == 1:
+            x = np.abs(rng.standard_normal(n)) * rng.random()
+        elif kind == 2:
+            x = rng.standard_normal(n) * 0.2
+            x[int(rng.integers(1, n)):] += rng.random() * 3
+        else:
+            x = np.round(rng.random(n) * 4) / 4  # repeated values: zero distances, exact ties between segmentations
+        for pen, gamma in ((5, None), (1.0, None), (5, 2.5)):
+            assert crw_hip.pelt_rbf(x, pen=pen, gamma=gamma) == pelt.pelt_rbf(x, pen=pen, gamma=gamma), (trial, n, pen, gamma)
+    for x in (np.zeros(50), [1.0], [1.0, 2.0], [1.0, 2.0, 3.0], np.arange(11.0)):
+        assert crw_hip.pelt_rbf(x, pen=5) == pelt.pelt_rbf(x, pen=5)
+    with pytest.raises(crw_hip.CrwError):
+        crw_hip.pelt_rbf([], pen=5)
+
+
 def test_pelt_pruning_keeps_the_exact_optimum():
     """PELT's defining property (Killick et al. 2012): with pruning it still returns the exact minimiser of
     sum of segment costs + pen * (number of segments) over the admissible grid (breakpoints at multiples of `jump`, segments of at
