@@ -936,6 +936,8 @@ def test_labelprop_matches_oracle_mcords_shape(hip):
     (256, 48, 128, 4, 80, 10, 20, 1),   # BASELINE config 5: 80 chained frames in one workgroup + 175 frames at once
     (14, 10, 16, 3, 3, 4, 5, 1),        # short chain, long tail
     (9, 12, 16, 3, 20, 3, 4, 1),        # T <= cxt + 1: every frame chained, no tail
+    (2, 10, 16, 3, 3, 4, 5, 1),         # two frames: one propagated frame (the seed path of the one-workgroup kernel)
+    (3, 9, 8, 2, 1, 2, 3, 1),           # three frames, cxt = 1: one chained frame + one tail frame
     (40, 63, 64, 6, 7, 5, 10, 1),       # 378 outputs per frame: six compute waves
     (30, 24, 32, 2, 1, 6, 24, 1),       # cxt = 1: frame 1 alone is chained; 24 neighbours (the widest register instance)
     (12, 30, 16, 3, 4, 3, 7, 5),        # 6 x 5 node grid
