@@ -16,8 +16,9 @@
 
 #pragma STDC FP_CONTRACT OFF
 
-extern "C" int crw_pelt_rbf(const double *signal, int n, double pen, int min_size, int jump, double gamma, int *bkps, int max_bkps) {
-  if (!signal || !bkps || n < 1 || min_size < 1 || jump < 1 || max_bkps < 1) return -CRW_EINVAL;
+static int pelt_rbf_impl(const double *signal, int n, double pen, int min_size, int jump, double gamma, int *bkps, int max_bkps) {
+  // (the Gram matrix is n x n doubles, like pelt.py's: 2 GiB at the bound)
+  if (!signal || !bkps || n < 1 || n > 16384 || min_size < 1 || jump < 1 || max_bkps < 1) return -CRW_EINVAL;
   const size_t N = (size_t)n;
   // Gram matrix K_ij = exp(-clip(gamma (x_i - x_j)^2, 1e-2, 1e2)), K_ii = 1; gamma <= 0: 1 / median of the pairwise squared
   // distances (mean of the two middle elements), 1 if that median is 0
@@ -136,4 +137,12 @@ extern "C" int crw_pelt_rbf(const double *signal, int n, double pen, int min_siz
   if ((int)out.size() > max_bkps) return -CRW_EINVAL;
   for (int v : out) bkps[cnt++] = v;
   return cnt;
+}
+
+extern "C" int crw_pelt_rbf(const double *signal, int n, double pen, int min_size, int jump, double gamma, int *bkps, int max_bkps) {
+  try {  // nothing is thrown across the ABI (the vectors above allocate)
+    return pelt_rbf_impl(signal, n, pen, min_size, jump, gamma, bkps, max_bkps);
+  } catch (...) {
+    return -CRW_EWORKSPACE;
+  }
 }
