@@ -344,6 +344,14 @@ int crw_rn_stem_stats(const float *x, int P, int cin, int h, int w, const float 
 int crw_rn_stem16_rows(void);
 int crw_rn_pack_stem16(const float *w1, uint16_t *wf, uint16_t *wt, crw_stream_t stream);
 int crw_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, const uint16_t *wf, float *Z1, float *part, crw_stream_t stream);
+/* The same forward product for patches of ANY size (what crw_rn_train_fwd / crw_rn_eval_fwd use beyond 16 x 16, e.g. the 32 x 32
+ * patches of scripts/test/test_mc1.py:19): a BAND of output rows per wave, the map rows it reads rebuilt from the patch in LDS.
+ * Z1 [P][H1 * W1][64] fp32 (H1, W1 = the 7x7/2 output of the (h+2) x (w+2) map), part as crw_rn_stem16_fwd's.
+ * crw_rn_stem_band_ok: 1 when the geometry is covered (output rows of at most 96 pixels, band image within the LDS), else 0 --
+ * then mode 2 of crw_rn_conv on the crw_rn_stem_fwd map planes is the way. */
+int crw_rn_stem_band_ok(int h, int w);
+int crw_rn_stem_band_fwd(const float *x, int P, int cin, int h, int w, const float *stem, const uint16_t *wf, float *Z1, float *part,
+                         crw_stream_t stream);
 size_t crw_rn_stem16_ws_bytes(void);
 int crw_rn_stem16_wgrad(const float *x, int P, int cin, const float *stem, const uint16_t *dz_hi, const uint16_t *dz_lo, float *dw, void *ws,
                         size_t ws_bytes, crw_stream_t stream);

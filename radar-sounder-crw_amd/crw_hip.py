@@ -103,6 +103,8 @@ SIGNATURES = {
     "crw_rn_stem16_rows": (_c_int, []),
     "crw_rn_pack_stem16": (_c_int, [_p, _p, _p, _p]),
     "crw_rn_stem16_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "crw_rn_stem_band_ok": (_c_int, [_c_int, _c_int]),
+    "crw_rn_stem_band_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "crw_rn_stem16_ws_bytes": (_c_sz, []),
     "crw_rn_stem16_wgrad": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _c_sz, _p]),
     "crw_rn_stem16_bwd": (_c_int, [_p, _c_int, _c_int] + [_p] * 11 + [_c_sz, _p]),
@@ -768,6 +770,20 @@ def rn_stem16_fwd(x, stem, wf):
     part = torch.empty(lib().crw_rn_stem16_rows(), 64, 2, dtype=torch.float32, device=x.device)
     _check(lib().crw_rn_stem16_fwd(_dev(x, "x"), P, cin, _dev(stem, "stem"), _bf(wf, "wf"), _dev(Z1, "Z1"), _dev(part, "part"),
                                    _stream()), "crw_rn_stem16_fwd")
+    return Z1, part
+
+
+def rn_stem_band_ok(h, w):
+    return bool(lib().crw_rn_stem_band_ok(int(h), int(w)))
+
+
+def rn_stem_band_fwd(x, stem, wf, H1, W1):
+    """the stem's forward product for patches of any size -> (Z1 [Ppad, H1*W1*64] fp32, part [rows, 64, 2])"""
+    P, cin, h, w = x.shape
+    Z1 = torch.zeros(rn_padded(P), H1 * W1 * 64, dtype=torch.float32, device=x.device)
+    part = torch.empty(lib().crw_rn_stem16_rows(), 64, 2, dtype=torch.float32, device=x.device)
+    _check(lib().crw_rn_stem_band_fwd(_dev(x, "x"), P, cin, h, w, _dev(stem, "stem"), _bf(wf, "wf"), _dev(Z1, "Z1"), _dev(part, "part"),
+                                      _stream()), "crw_rn_stem_band_fwd")
     return Z1, part
 
 

@@ -124,6 +124,10 @@ int rn_stem16_blocks();
 int launch_rn_pack_stem_frag(const float *w1, uint16_t *wf, uint16_t *wt, hipStream_t s);
 int launch_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, const uint16_t *wf, float *Z1, float *part /* [blocks*8][64][2] */,
                          hipStream_t s);
+// the same forward product for patches of any size, a band of output rows per wave (false: geometry not covered)
+bool rn_stem_band_ok(int h, int w);
+int launch_rn_stem_band_fwd(const float *x, int P, int cin, int h, int w, const float *stem, const uint16_t *wf, float *Z1,
+                            float *part /* [blocks*8][64][2] */, hipStream_t s);
 int launch_rn_stem16_wgrad(const float *x, int P, int cin, const float *stem, const uint16_t *dz_hi, const uint16_t *dz_lo,
                            float *slab /* [blocks*4][224][64] */, hipStream_t s);
 int launch_rn_stem16_bwd(const float *x, int P, int cin, const float *stem, const float *w0, const float *b0, const uint16_t *wt,

@@ -288,6 +288,15 @@ int crw_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, const u
   return launch_rn_stem16_fwd(x, P, cin, stem, wf, Z1, part, (hipStream_t)stream);
 }
 
+int crw_rn_stem_band_ok(int h, int w) { return rn_stem_band_ok(h, w) ? 1 : 0; }
+
+int crw_rn_stem_band_fwd(const float *x, int P, int cin, int h, int w, const float *stem, const uint16_t *wf, float *Z1, float *part,
+                         crw_stream_t stream) {
+  clear_stale_error();
+  if (!x || !stem || !wf || !Z1 || !part || P < 1 || cin < 1 || cin > 2 || !rn_stem_band_ok(h, w)) return CRW_EINVAL;
+  return launch_rn_stem_band_fwd(x, P, cin, h, w, stem, wf, Z1, part, (hipStream_t)stream);
+}
+
 size_t crw_rn_stem16_ws_bytes(void) {
   return align_up((size_t)rn_stem16_blocks() * 4 * 224 * 64 * 4, 256) + (size_t)rn_stem16_blocks() * 8 * 16 * 4 + 64 * 16 * 8 + 256;
 }

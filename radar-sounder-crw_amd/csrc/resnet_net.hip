@@ -49,6 +49,8 @@ struct Plan {
   float *stem;
   uint16_t *wsf_h, *wsf_l, *wst_h, *wst_l;
   bool stem16;           // 16 x 16 patches: the patch-per-wave stem kernels (resnet_stem.hip), no map / Toeplitz planes in HBM
+  bool band;             // other sizes the band kernel covers: the stem's FORWARD product on rn_stem_fwd_band_kernel (a band of output
+                         // rows per wave); the backward pass keeps the map / Toeplitz planes
   uint16_t *w16f, *w16t;  // their weight fragment packs
   float *stem_part;
   Planes xmap, A1;
@@ -102,9 +104,12 @@ struct Plan {
     const size_t pp = (size_t)Ppad;
     stem = take<float>(32);
     stem16 = (h == 16 && w == 16);
-    if (stem16) {
+    band = !stem16 && rn_stem_band_ok(h, w);
+    if (stem16 || band) {
       w16f = take<uint16_t>(RN_STEM_FRAG_ELEMS);
       w16t = take<uint16_t>(RN_STEM_FRAG_ELEMS);
+    }
+    if (stem16) {
       stem_part = take<float>((size_t)rn_stem16_blocks() * 8 * 16);
     } else {
       wsf_h = take<uint16_t>(64 * 256); wsf_l = take<uint16_t>(64 * 256);
@@ -349,17 +354,27 @@ int forward_pass(bool training, const float *x, int P, int cin, int h, int w, co
     }
     CRW_TRY(bn_coef(pl.part, rn_stem16_blocks() * 8, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
   } else {
-    CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.ncols, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, s));
-    if (training) {
+    // the Toeplitz / row packs of the 7x7 weights: with the band kernel only the backward pass reads them -- beside the stem then
+    CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.ncols, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, pl.band ? sw : s));
+    if (pl.band) CRW_TRY(launch_rn_pack_stem_frag(prm[4], pl.w16f, pl.w16t, s));
+    if (training) {  // (bn0's statistics; the 4-channel map planes are what the backward pass multiplies)
       CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
                                  pl.xmap.lo, pl.stem, pl.stem_ws, s));
     } else {
       CRW_TRY(launch_rn_stem_eval(cin, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), eps, pl.stem, s));
-      CRW_TRY(launch_rn_stem_apply(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, pl.stem, pl.xmap.hi, pl.xmap.lo, s));
+      if (!pl.band) CRW_TRY(launch_rn_stem_apply(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, pl.stem, pl.xmap.hi, pl.xmap.lo, s));
     }
-    CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1,
-                 training ? pl.part : nullptr));
-    CRW_TRY(bn_coef(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
+    if (pl.band) {  // the product itself: a band of output rows per wave, map rebuilt from the patch in LDS (resnet_stem.hip)
+      {
+        Timed t(s, 0, RN_MODE_STEM_FWD, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3);
+        CRW_TRY(launch_rn_stem_band_fwd(x, P, cin, h, w, pl.stem, pl.w16f, pl.Z1, pl.part, s));
+      }
+      CRW_TRY(bn_coef(pl.part, rn_stem16_blocks() * 8, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
+    } else {
+      CRW_TRY(conv(s, RN_MODE_STEM_FWD, P, pl.Hm, pl.Wm, 4, pl.H1, pl.W1, 64, 7, 2, 3, pl.xmap, pl.wsf_h, pl.wsf_l, nullptr, pl.Z1,
+                   training ? pl.part : nullptr));
+      CRW_TRY(bn_coef(pl.part, (pl.Ppad / 128) * 2 * pl.H1 * pl.W1, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
+    }
   }
   CRW_TRY(launch_rn_bn_pool(pl.Z1, pl.coef1, P, pl.Ppad, pl.H1, pl.W1, 64, pl.A1.hi, pl.A1.lo, pl.amax1, s));
 

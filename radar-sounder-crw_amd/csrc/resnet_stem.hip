@@ -14,6 +14,8 @@
 //     row at a time, and is gathered into the 18x18x3 gradient in registers (ds_add_f32 into an LDS image measured 5x slower)
 //     -- the gradient map never reaches HBM: only the 12 sums that bn0 / fc0 need leave the kernel.
 // 504 MFMAs per patch and pass (6 x 4 x 7 x 3 | 14 x 4 x 3 x 3 | 6 x 14 x 2 x 3), hi / lo operand pairs as everywhere.
+#include <cstdlib>
+
 #include "crw_common.h"
 #include "resnet.h"
 
@@ -170,6 +172,156 @@ __global__ __launch_bounds__(512) void rn_stem_fwd_kernel(const float *__restric
       }
   }
   // BatchNorm statistics of this wave's patches: one partial row per wave
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float a = s1[j], b = s2[j];
+    a += __shfl_xor(a, 16);
+    b += __shfl_xor(b, 16);
+    a += __shfl_xor(a, 32);
+    b += __shfl_xor(b, 32);
+    if (lane < 16) reinterpret_cast<float2 *>(part)[(long)gw * 64 + 16 * j + lane] = float2{a, b};
+  }
+}
+
+// ================================================================================================ forward, any patch size
+// The same product for patches of any size (32 x 32 at BASELINE config 5: a 17 x 17 x 64 output map per patch, where the gathered
+// product of resnet_gemm.hip stages 5.3 GB of 64-byte row pieces for it: 0.71 ms of a 4.6 ms pass).  A wave owns a BAND of RB output
+// rows of a patch (at most BAND_MT row tiles of 16 output pixels); the map rows the band reads -- 2 RB + 5 of them, MW pixels wide --
+// are rebuilt from the patch into the wave's own LDS image exactly like above (interior: relu0(bn0(fc0(x))); the ring where fc0
+// sees only its bias; zeros for the convolution's own padding), the im2col gather is an LDS read, the weights stay resident in LDS.
+// Z1 [P][H1 * W1][64] and the per-wave BatchNorm partial sums leave the kernel as in rn_stem_fwd_kernel.
+constexpr int BAND_MT = 6;
+struct StemBand {
+  int h, w, H1, W1;  // patch size, output map of the 7x7/2 convolution
+  int RB, NB;        // output rows per band, bands per patch
+  int MW, MR;        // band image: MR = 2 RB + 5 map rows of MW pixels (MW even: every fragment read stays 16-byte aligned)
+};
+
+template <int CIN>
+__global__ __launch_bounds__(512) void rn_stem_fwd_band_kernel(const float *__restrict__ x, const float *__restrict__ stem,
+                                                               const uint16_t *__restrict__ wfrag, int P, StemBand g,
+                                                               float *__restrict__ Z1, float *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int plane = g.MR * g.MW * 8;
+  char *wl = lds;
+  char *map = lds + WFRAG_BYTES + wave * 2 * plane;
+  const StemCoef k = load_coef(stem);
+  for (int i = threadIdx.x; i < WFRAG_BYTES / 16; i += 512)
+    reinterpret_cast<uint4 *>(wl)[i] = reinterpret_cast<const uint4 *>(wfrag)[i];
+  __syncthreads();
+  uint2 ring_h, ring_l;
+  stem_pixel(k, 0.f, 0.f, ring_h, ring_l);
+  constexpr int FILL_G = 4;
+  const int npair = g.MW >> 1, rpi = 64 / npair;               // pixel pairs per image row; image rows a wave fills per pass
+  const int rl = lane / npair, cp = lane - rl * npair;
+  const bool active = rl < rpi;
+
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int gw = blockIdx.x * 8 + wave, tw = gridDim.x * 8;
+  const long units = (long)P * g.NB;
+  for (long u = gw; u < units; u += tw) {  // (wave-uniform)
+    const int p = (int)(u / g.NB), b = (int)(u - (long)p * g.NB);
+    const int oy0 = b * g.RB, rb = min(g.RB, g.H1 - oy0), npx = rb * g.W1, nt = (npx + 15) >> 4, nr = 2 * rb + 5;
+    // band image: map row 2 oy0 + r, r < nr.  Map pixel (my, mx) is fc0-map pixel (my - 3, mx - 3) = patch pixel (my - 4, mx - 4)
+    const float *xp = x + (long)p * CIN * g.h * g.w;
+    // a lane owns a pixel PAIR of the image row (column pair cp, 16 bytes per plane) in every rpi-th row: no division in the
+    // loop, the patch values of FILL_G rows requested together
+    for (int r0 = rl; r0 < nr; r0 += FILL_G * rpi) {
+      float xa[FILL_G][2], xb[FILL_G][2];
+#pragma unroll
+      for (int t = 0; t < FILL_G; ++t) {
+        const int iy = 2 * oy0 + r0 + t * rpi - 4;
+        const bool rowin = (unsigned)iy < (unsigned)g.h;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ix = 2 * cp + e - 4;
+          const bool inside = active && rowin && (unsigned)ix < (unsigned)g.w;
+          const int off = inside ? iy * g.w + ix : 0;  // (clamped, unconditional loads)
+          xa[t][e] = xp[off];
+          xb[t][e] = CIN == 2 ? xp[g.h * g.w + off] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < FILL_G; ++t) {
+        const int r = r0 + t * rpi, my = 2 * oy0 + r, iy = my - 4;
+        if (active && r < nr) {
+          uint2 hi[2], lo[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int mx = 2 * cp + e, ix = mx - 4;
+            const bool inside = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+            const bool ring = my >= 3 && my < g.h + 5 && mx >= 3 && mx < g.w + 5;
+            stem_pixel(k, xa[t][e], xb[t][e], hi[e], lo[e]);
+            if (!inside) {
+              hi[e] = ring ? ring_h : uint2{0u, 0u};
+              lo[e] = ring ? ring_l : uint2{0u, 0u};
+            }
+          }
+          char *dst = map + (r * g.MW + 2 * cp) * 8;
+          *reinterpret_cast<uint4 *>(dst) = uint4{hi[0].x, hi[0].y, hi[1].x, hi[1].y};
+          *reinterpret_cast<uint4 *>(dst + plane) = uint4{lo[0].x, lo[0].y, lo[1].x, lo[1].y};
+        }
+      }
+    }
+    // this lane's fragment rows: row tile i, band pixel o = 16 i + (lane & 15), column group lane >> 4
+    int abase[BAND_MT];
+#pragma unroll
+    for (int i = 0; i < BAND_MT; ++i) {
+      const int o = min(16 * i + (lane & 15), npx - 1);  // rows past the band: computed, never stored
+      const int oy = o / g.W1, ox = o - oy * g.W1;
+      abase[i] = ((2 * oy) * g.MW + 2 * ox + 2 * (lane >> 4)) * 8;
+    }
+    f32x4 acc[BAND_MT][4];
+#pragma unroll
+    for (int i = 0; i < BAND_MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rowb = g.MW * 8;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      bf8 bq[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bq[j] = *reinterpret_cast<const bf8 *>(wl + ((ky * 4 + j) * 2 + 0) * 1024 + lane * 16);
+        bl[j] = *reinterpret_cast<const bf8 *>(wl + ((ky * 4 + j) * 2 + 1) * 1024 + lane * 16);
+      }
+#pragma unroll
+      for (int i0 = 0; i0 < BAND_MT; i0 += 3) {  // three row tiles' fragments at a time (all six: past the register file)
+        bf8 a[3], al[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {  // (tiles past nt read the band's last pixel: valid addresses)
+          a[i] = *reinterpret_cast<const bf8 *>(map + abase[i0 + i] + ky * rowb);
+          al[i] = *reinterpret_cast<const bf8 *>(map + plane + abase[i0 + i] + ky * rowb);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i0 + i < nt) {  // scalar branch: the matrix instructions ignore EXEC
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[i0 + i][j] = mfma(al[i], bq[j], acc[i0 + i][j]);
+              acc[i0 + i][j] = mfma(a[i], bl[j], acc[i0 + i][j]);
+              acc[i0 + i][j] = mfma(a[i], bq[j], acc[i0 + i][j]);
+            }
+          }
+      }
+    }
+    float *zp = Z1 + ((long)p * g.H1 * g.W1 + (long)oy0 * g.W1) * 64;
+#pragma unroll
+    for (int i = 0; i < BAND_MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * i + (lane >> 4) * 4 + r;
+        if (o < npx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = acc[i][j][r];
+            zp[o * 64 + 16 * j + (lane & 15)] = v;
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+      }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float a = s1[j], b = s2[j];
@@ -497,6 +649,40 @@ int launch_rn_stem16_fwd(const float *x, int P, int cin, const float *stem, cons
   } else {
     if (!set2) { CRW_TRY(set_lds(rn_stem_fwd_kernel<2>, lds)); set2 = true; }
     hipLaunchKernelGGL(rn_stem_fwd_kernel<2>, dim3(rn_stem16_blocks()), dim3(512), lds, s, x, stem, wf, P, Z1, part);
+  }
+  return check_launch();
+}
+
+// The band kernel's geometry for h x w patches; false: not covered (the gathered product of resnet_gemm.hip takes the layer)
+static bool stem_band_geometry(int h, int w, StemBand &g) {
+  g.h = h; g.w = w;
+  g.H1 = (h + 2 + 6 - 7) / 2 + 1; g.W1 = (w + 2 + 6 - 7) / 2 + 1;
+  if (h < 1 || w < 1 || g.W1 > 16 * BAND_MT || w + 9 > 128) return false;  // (an image row of at most 64 pixel pairs)
+  g.RB = (16 * BAND_MT) / g.W1;
+  if (g.RB > g.H1) g.RB = g.H1;
+  g.NB = (g.H1 + g.RB - 1) / g.RB;
+  g.MW = (w + 8 + 1) & ~1;
+  g.MR = 2 * g.RB + 5;
+  return WFRAG_BYTES + (size_t)8 * 2 * g.MR * g.MW * 8 <= (size_t)160 * 1024;
+}
+bool rn_stem_band_ok(int h, int w) {
+  StemBand g;
+  static const bool off = getenv("CRW_RN_STEM_BAND") && getenv("CRW_RN_STEM_BAND")[0] == '0';  // A/B: the gathered product
+  return !off && stem_band_geometry(h, w, g);
+}
+// Z1 [P][H1 * W1][64] fp32, part [blocks * 8][64] float2 -- rn_stem_fwd_kernel's outputs for patches of any size
+int launch_rn_stem_band_fwd(const float *x, int P, int cin, int h, int w, const float *stem, const uint16_t *wf, float *Z1, float *part,
+                            hipStream_t s) {
+  StemBand g;
+  if (!stem_band_geometry(h, w, g) || (cin != 1 && cin != 2)) return CRW_EINVAL;
+  const size_t lds = WFRAG_BYTES + (size_t)8 * 2 * g.MR * g.MW * 8;
+  static size_t set1 = 0, set2 = 0;  // dynamic-LDS limit raised so far, per instantiation
+  if (cin == 1) {
+    if (set1 < lds) { CRW_TRY(set_lds(rn_stem_fwd_band_kernel<1>, (size_t)160 * 1024)); set1 = (size_t)160 * 1024; }
+    hipLaunchKernelGGL(rn_stem_fwd_band_kernel<1>, dim3(rn_stem16_blocks()), dim3(512), lds, s, x, stem, wf, P, g, Z1, part);
+  } else {
+    if (set2 < lds) { CRW_TRY(set_lds(rn_stem_fwd_band_kernel<2>, (size_t)160 * 1024)); set2 = (size_t)160 * 1024; }
+    hipLaunchKernelGGL(rn_stem_fwd_band_kernel<2>, dim3(rn_stem16_blocks()), dim3(512), lds, s, x, stem, wf, P, g, Z1, part);
   }
   return check_launch();
 }

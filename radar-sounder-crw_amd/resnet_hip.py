@@ -158,8 +158,12 @@ class HipResnetFn(torch.autograd.Function):
         else:
             wstem = H.rn_pack_stem(body.conv1.weight, h, w)
             xmap, stem = H.rn_stem_fwd(x, net.fc0, net.bn0, Hm, Wm, mom)
-            Z1, part = H.rn_conv(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1), 64, (7, 7), 2, 3, xmap, wstem[:2], stats=True)
-            coef1 = H.rn_bn_stats(part, P, H1 * W1, body.bn1, mom)
+            if H.rn_stem_band_ok(h, w):  # like the native pass: the forward product on the band-per-wave kernel (csrc/resnet_stem.hip)
+                Z1, part = H.rn_stem_band_fwd(x, stem, H.rn_pack_stem16(body.conv1.weight)[0], H1, W1)
+                coef1 = H.rn_bn_stats_rows(part, P * H1 * W1, body.bn1, mom)
+            else:
+                Z1, part = H.rn_conv(H.RN_STEM_FWD, P, (Hm, Wm, 4), (H1, W1), 64, (7, 7), 2, 3, xmap, wstem[:2], stats=True)
+                coef1 = H.rn_bn_stats(part, P, H1 * W1, body.bn1, mom)
         A, amax = H.rn_bn_pool(Z1, coef1, P, H1, W1, 64)
         sv.update(wstem=wstem, xmap=xmap, stem=stem, Z1=Z1, coef1=coef1, amax=amax)
 

@@ -33,6 +33,9 @@ VARIANTS = [
     # default release + acquire fence (csrc/resnet_bn.hip rn_sums_tail_kernel)
     ("CRW_RN_TICKET", "relaxed", RESNET, "native_and_stepwise or training_step or reproducible"),
     ("CRW_RN_TICKET", "acqrel", RESNET, "native_and_stepwise or reproducible"),
+    # the stem's forward product at other patch sizes than 16 x 16 on the gathered product of resnet_gemm.hip where the default is the
+    # band-per-wave kernel (csrc/resnet_stem.hip rn_stem_fwd_band_kernel)
+    ("CRW_RN_STEM_BAND", "0", RESNET, "matches_pytorch_modules or inference_through_propagate or training_step_matches_reference"),
     # label-propagation top-k on the vector kernel where the default scores on the fp32 matrix cores (csrc/labelprop.hip)
     ("CRW_LABELPROP_TOPK_VALU", "1", PARITY, "labelprop_matches_oracle_mcords_shape or labelprop_edge_cases or propagate_matches_reference"),
 ]
