@@ -212,16 +212,17 @@ __global__ __launch_bounds__(512) void rn_stem_fwd_band_kernel(const float *__re
   __syncthreads();
   uint2 ring_h, ring_l;
   stem_pixel(k, 0.f, 0.f, ring_h, ring_l);
-  constexpr int FILL_G = 4;
+  constexpr int FILL_G = 3;
   const int npair = g.MW >> 1, rpi = 64 / npair;               // pixel pairs per image row; image rows a wave fills per pass
   const int rl = lane / npair, cp = lane - rl * npair;
   const bool active = rl < rpi;
 
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int gw = blockIdx.x * 8 + wave, tw = gridDim.x * 8;
-  const long units = (long)P * g.NB;
-  for (long u = gw; u < units; u += tw) {  // (wave-uniform)
-    const int p = (int)(u / g.NB), b = (int)(u - (long)p * g.NB);
+  // a wave takes whole patches, band after band: every wave the same mix of full and short bands (bands dealt out one by one
+  // gave a wave the SAME band of every patch whenever the wave count is a multiple of NB -- the short last band's waves idled)
+  for (int p = gw; p < P; p += tw)
+  for (int b = 0; b < g.NB; ++b) {  // (wave-uniform)
     const int oy0 = b * g.RB, rb = min(g.RB, g.H1 - oy0), npx = rb * g.W1, nt = (npx + 15) >> 4, nr = 2 * rb + 5;
     // band image: map row 2 oy0 + r, r < nr.  Map pixel (my, mx) is fc0-map pixel (my - 3, mx - 3) = patch pixel (my - 4, mx - 4)
     const float *xp = x + (long)p * CIN * g.h * g.w;
