@@ -383,6 +383,12 @@ int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *
                      float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
 int crw_rn_train_bwd(const float *dout, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *grads,
                      void *ws, size_t ws_bytes, crw_stream_t stream);
+/* crw_rn_train_fwd when NO backward pass follows (the reference's test scripts: train-mode BatchNorm under torch.no_grad(),
+ * scripts/test/test_mc1.py:40-46 with src/utils.py:108): same out, same running-statistics update; what only crw_rn_train_bwd
+ * would read (the stem's map planes and Toeplitz weight packs at patch sizes other than 16 x 16) is not produced -- the workspace
+ * must NOT be handed to crw_rn_train_bwd afterwards. */
+int crw_rn_train_fwd_nograd(const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
+                            float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream);
 /* The same forward with every BatchNorm in EVAL mode (nn.Module.eval(): normalise by the running statistics, update nothing) --
  * what the reference's scripts/test/test.py:42 runs before utils.propagate.  ws: crw_rn_train_ws_bytes. */
 int crw_rn_eval_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, const float *const *run_mean,

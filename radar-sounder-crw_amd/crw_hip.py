@@ -110,6 +110,7 @@ SIGNATURES = {
     "crw_rn_stem16_bwd": (_c_int, [_p, _c_int, _c_int] + [_p] * 11 + [_c_sz, _p]),
     "crw_rn_train_ws_bytes": (_c_sz, [_c_int] * 4),
     "crw_rn_train_fwd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
+    "crw_rn_train_fwd_nograd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _c_f, _p, _p, _c_sz, _p]),
     "crw_rn_train_bwd": (_c_int, [_p, _p] + [_c_int] * 4 + [_p, _p, _p, _c_sz, _p]),
     "crw_rn_eval_fwd": (_c_int, [_p] + [_c_int] * 4 + [_p, _p, _p, _c_f, _p, _p, _c_sz, _p]),
     "crw_rn_stem_cols": (_c_int, [_c_int]),
@@ -856,19 +857,21 @@ def _ptr_array(tensors, n):
     return (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
 
 
-def rn_train_fwd(x, params, run_mean, run_var, momentum, eps):
+def rn_train_fwd(x, params, run_mean, run_var, momentum, eps, keep=True):
     """x [P,cin,h,w]; params: the 42 parameter tensors in named_parameters() order; run_mean / run_var: the 13 BatchNorm buffer
-    pairs in module order (updated in place) -> (out [P,128], workspace kept for rn_train_bwd)."""
+    pairs in module order (updated in place) -> (out [P,128], workspace kept for rn_train_bwd).  keep=False: no backward pass
+    follows (crw_rn_train_fwd_nograd) -> (out, None)."""
     P, cin, h, w = x.shape
     nbytes = lib().crw_rn_train_ws_bytes(P, cin, h, w)
     if nbytes == 0:
         raise RuntimeError(f"crw_rn_train_fwd: unsupported input {tuple(x.shape)}")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     out = torch.empty(P, 128, dtype=torch.float32, device=x.device)
-    _check(lib().crw_rn_train_fwd(_dev(x, "x"), P, cin, h, w, _ptr_array(params, RN_NPARAM), _ptr_array(run_mean, RN_NBN),
-                                  _ptr_array(run_var, RN_NBN), float(momentum), float(eps), _dev(out, "out"), _ptr(ws), nbytes,
-                                  _stream()), "crw_rn_train_fwd")
-    return out, ws
+    fn = lib().crw_rn_train_fwd if keep else lib().crw_rn_train_fwd_nograd
+    _check(fn(_dev(x, "x"), P, cin, h, w, _ptr_array(params, RN_NPARAM), _ptr_array(run_mean, RN_NBN),
+              _ptr_array(run_var, RN_NBN), float(momentum), float(eps), _dev(out, "out"), _ptr(ws), nbytes,
+              _stream()), "crw_rn_train_fwd" if keep else "crw_rn_train_fwd_nograd")
+    return out, (ws if keep else None)
 
 
 def rn_eval_fwd(x, params, run_mean, run_var, eps):

@@ -293,7 +293,9 @@ struct SideJoin {
 
 // The forward pass.  training: BatchNorm on batch statistics (+ running-statistics update when run_mean / run_var are given);
 // otherwise (nn.Module.eval(), the reference's scripts/test/test.py:42) BatchNorm on the RUNNING statistics, nothing updated.
-int forward_pass(bool training, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
+// keep: a backward pass may follow (crw_rn_train_bwd reads the workspace); false: what only that pass would read is not produced
+// (the stem's 4-channel map planes and Toeplitz weight packs at patch sizes on the band kernel)
+int forward_pass(bool training, bool keep, const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
                  float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, hipStream_t s) {
   if (!x || !prm || !out || !ws || P < 1 || (run_mean == nullptr) != (run_var == nullptr) || (!training && !run_mean)) return CRW_EINVAL;
   for (int i = 0; i < NPARAM; ++i)
@@ -355,11 +357,15 @@ int forward_pass(bool training, const float *x, int P, int cin, int h, int w, co
     CRW_TRY(bn_coef(pl.part, rn_stem16_blocks() * 8, 64, (double)P * pl.H1 * pl.W1, prm[5], prm[6], 1, pl.coef1, pl.stats_ws, s));
   } else {
     // the Toeplitz / row packs of the 7x7 weights: with the band kernel only the backward pass reads them -- beside the stem then
-    CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.ncols, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, pl.band ? sw : s));
+    const bool planes_needed = !pl.band || (training && keep);  // the gathered forward product, or the backward pass, reads them
+    if (planes_needed)
+      CRW_TRY(launch_rn_pack_stem(prm[4], pl.H0, pl.W0, pl.H1, pl.W1, pl.ldt, pl.ncols, pl.wsf_h, pl.wsf_l, pl.wst_h, pl.wst_l, pl.band ? sw : s));
     if (pl.band) CRW_TRY(launch_rn_pack_stem_frag(prm[4], pl.w16f, pl.w16t, s));
-    if (training) {  // (bn0's statistics; the 4-channel map planes are what the backward pass multiplies)
+    if (training && planes_needed) {  // (bn0's statistics; the 4-channel map planes are what the backward pass multiplies)
       CRW_TRY(launch_rn_stem_fwd(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.xmap.hi,
                                  pl.xmap.lo, pl.stem, pl.stem_ws, s));
+    } else if (training) {            // bn0's statistics alone
+      CRW_TRY(launch_rn_stem_stats(x, P, cin, h, w, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), momentum, eps, pl.stem, pl.stem_ws, s));
     } else {
       CRW_TRY(launch_rn_stem_eval(cin, prm[0], prm[1], prm[2], prm[3], rm(0), rv(0), eps, pl.stem, s));
       if (!pl.band) CRW_TRY(launch_rn_stem_apply(x, P, pl.Ppad, cin, h, w, pl.Hm, pl.Wm, pl.stem, pl.xmap.hi, pl.xmap.lo, s));
@@ -428,13 +434,19 @@ size_t crw_rn_train_ws_bytes(int P, int cin, int h, int w) {
 int crw_rn_train_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
                      float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
-  return forward_pass(true, x, P, cin, h, w, prm, run_mean, run_var, momentum, eps, out, ws, ws_bytes, (hipStream_t)stream);
+  return forward_pass(true, true, x, P, cin, h, w, prm, run_mean, run_var, momentum, eps, out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int crw_rn_train_fwd_nograd(const float *x, int P, int cin, int h, int w, const float *const *prm, float *const *run_mean,
+                            float *const *run_var, float momentum, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream) {
+  clear_stale_error();
+  return forward_pass(true, false, x, P, cin, h, w, prm, run_mean, run_var, momentum, eps, out, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int crw_rn_eval_fwd(const float *x, int P, int cin, int h, int w, const float *const *prm, const float *const *run_mean,
                     const float *const *run_var, float eps, float *out, void *ws, size_t ws_bytes, crw_stream_t stream) {
   clear_stale_error();
-  return forward_pass(false, x, P, cin, h, w, prm, const_cast<float *const *>(reinterpret_cast<const float *const *>(run_mean)),
+  return forward_pass(false, false, x, P, cin, h, w, prm, const_cast<float *const *>(reinterpret_cast<const float *const *>(run_mean)),
                       const_cast<float *const *>(reinterpret_cast<const float *const *>(run_var)), 0.f, eps, out, ws, ws_bytes,
                       (hipStream_t)stream);
 }

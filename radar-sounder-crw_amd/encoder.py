@@ -305,6 +305,8 @@ class Resnet(nn.Module):
             if resnet_hip.supported(x, self):
                 if not self.training:
                     return resnet_hip.eval_forward(x, self)
+                if not torch.is_grad_enabled() and self.hip_convs != "stepwise":  # train-mode BatchNorm, no backward to follow
+                    return resnet_hip.nograd_forward(x, self)
                 fn = resnet_hip.HipResnetFn if self.hip_convs == "stepwise" else resnet_hip.HipResnetNative
                 return fn.apply(x, self, *self.parameters())
             if not Resnet._warned_fallback:

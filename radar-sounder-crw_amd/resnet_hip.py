@@ -121,6 +121,17 @@ class HipResnetNative(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def nograd_forward(x, net):
+    """Train-mode BatchNorm under ``torch.no_grad()`` -- how the reference's test scripts run the encoder (scripts/test/test_mc1.py:
+    40-46 never calls .eval(); src/utils.py:108): crw_rn_train_fwd without what only a backward pass would read."""
+    check_batch(x)
+    bns = _bn_modules(net)
+    out, _ = H.rn_train_fwd(x.contiguous(), [p.detach().contiguous() for p in net.parameters()], [m.running_mean for m in bns],
+                            [m.running_var for m in bns], net.bn0.momentum, net.bn0.eps, keep=False)
+    torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+    return out
+
+
 def eval_forward(x, net):
     """``net.eval()`` under ``torch.no_grad()``: the same launches with every BatchNorm on its running statistics (crw_rn_eval_fwd)"""
     bns = _bn_modules(net)
