@@ -888,18 +888,26 @@ def rn_eval_fwd(x, params, run_mean, run_var, eps):
     return out
 
 
-def rn_train_bwd(dout, x, params, ws):
-    """-> the 42 gradients (views of one flat buffer), in the order of `params`"""
-    P, cin, h, w = x.shape
+def rn_grad_views(params):
+    """the 42 gradient tensors of crw_rn_train_bwd as views of one flat buffer + the two pointer arrays of the call.  Built at
+    FORWARD time by the autograd function: the host is ahead of the GPU there, while at the start of the backward pass the GPU has
+    just run the walk's few small kernels and would wait ~50 us for these 42 views."""
     sizes = [p.numel() for p in params]
     starts, tot = [], 0
     for n in sizes:
         starts.append(tot)
         tot += (n + 3) // 4 * 4  # 16-byte aligned views
-    flat = torch.empty(tot, dtype=torch.float32, device=x.device)
+    flat = torch.empty(tot, dtype=torch.float32, device=params[0].device)
     grads = [flat[o:o + n].view(p.shape) for o, n, p in zip(starts, sizes, params)]
-    _check(lib().crw_rn_train_bwd(_dev(dout, "dout"), _dev(x, "x"), P, cin, h, w, _ptr_array(params, RN_NPARAM),
-                                  _ptr_array(grads, RN_NPARAM), _ptr(ws), ws.numel(), _stream()), "crw_rn_train_bwd")
+    return grads, _ptr_array(params, RN_NPARAM), _ptr_array(grads, RN_NPARAM)
+
+
+def rn_train_bwd(dout, x, params, ws, prepared=None):
+    """-> the 42 gradients (views of one flat buffer), in the order of `params`; prepared: rn_grad_views(params) made earlier"""
+    P, cin, h, w = x.shape
+    grads, pp, gp = prepared if prepared is not None else rn_grad_views(params)
+    _check(lib().crw_rn_train_bwd(_dev(dout, "dout"), _dev(x, "x"), P, cin, h, w, pp, gp, _ptr(ws), ws.numel(), _stream()),
+           "crw_rn_train_bwd")
     return grads
 
 

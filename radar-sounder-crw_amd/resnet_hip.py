@@ -110,14 +110,15 @@ class HipResnetNative(torch.autograd.Function):
         out, ws = H.rn_train_fwd(x, prm, [m.running_mean for m in bns], [m.running_var for m in bns], net.bn0.momentum, net.bn0.eps)
         torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         ctx.x, ctx.ws, ctx.prm = x, ws, prm
+        ctx.prepared = H.rn_grad_views(prm)  # (now, while the host is ahead of the GPU: see there)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         if ctx.needs_input_grad[0]:
             raise RuntimeError("the HIP Resnet path does not produce a gradient for its input patches (the reference never asks for one)")
-        grads = H.rn_train_bwd(dout.contiguous().float(), ctx.x, ctx.prm, ctx.ws)
-        ctx.ws = None
+        grads = H.rn_train_bwd(dout.contiguous().float(), ctx.x, ctx.prm, ctx.ws, ctx.prepared)
+        ctx.ws = ctx.prepared = None
         return (None, None) + tuple(grads)
 
 
