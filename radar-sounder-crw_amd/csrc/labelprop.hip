@@ -13,7 +13,6 @@
 // [frame 0, last cxt frames] but are applied to the untruncated label list.
 #include "crw_common.h"
 #include <cstdlib>
-#include <type_traits>
 
 namespace crw {
 namespace {
@@ -453,8 +452,8 @@ __global__ __launch_bounds__(GATHER_NT) void labelprop_gather_lds_kernel(const f
 //     and weights already in registers), the sum in neighbour order, the LDS + global store, then the NEXT frame's (index, weight)
 //     reads from an LDS copy while the barrier gathers; loader waves, one frame each in rotation, keep the lists of the next frames
 //     in flight from global memory and copy them into a double-buffered LDS slot two frames ahead; one more wave takes the
-//     arg-max / pred store of the previous frame.  The per-frame barrier waits for LDS traffic only (lds_barrier): global loads and stores stay in flight
-//     across frames, where labelprop_gather_lds_kernel's __syncthreads() drained them every frame (2.4 us per frame at cfg5).
+//     arg-max / pred store of the previous frame.  The per-frame barrier waits for LDS traffic only (lds_barrier): global loads and
+//     stores stay in flight across frames, where labelprop_gather_lds_kernel's __syncthreads() drained them every frame (2.4 us per frame at cfg5).
 //   tail kernel: a workgroup per frame n > cxt, all at once, labels gathered from L in global memory (complete since the prefix).
 // Same operations in the same order per output as the kernels above: bit-identical L and pred.
 constexpr int PX_PF = 16, PX_NT = 512;  // list entries per loader lane and frame (a frame's lists: knn * N <= 64 * PX_PF); threads at most
