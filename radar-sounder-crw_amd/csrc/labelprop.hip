@@ -128,13 +128,17 @@ __global__ __launch_bounds__(256) void labelprop_topk_kernel(const float *__rest
 // registers (TK_NV per lane and query) -- no workgroup barrier inside the knn rounds --, same rule: highest value, then lowest candidate index.
 constexpr int TK_Q = 16, TK_NV = 32, TK_NT = 512, TK_NW = TK_NT / 64;  // eight waves: two per SIMD cover each other's round trips
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <int CSTEPS>  // C / 16: float4 per lane and row
-__global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float *__restrict__ ehat, int T, int N, int cxt, int radius, float temp,
-                                                                  int knn, int first_frame, int maxcand, float *__restrict__ W,
+// NCH = 2: the context frames in two halves, one after the other through HALF the score buffer (two workgroups per CU: one's
+// scoring -- matrix cores, loads, LDS scatter -- runs beside the other's selection -- vector compares), the first half's k best
+// carried into the second selection as extra candidates: top-k(A u B) = top-k(top-k(A) u B), and the carried candidates have the
+// lower indices, so "highest value, then lowest candidate index" picks the same list.  pf = context frames per chunk.
+template <int CSTEPS, int NCH>  // C / 16: float4 per lane and row
+__global__ __launch_bounds__(TK_NT, 2 * NCH) void labelprop_topk_mfma_kernel(const float *__restrict__ ehat, int T, int N, int cxt, int radius, float temp,
+                                                                  int knn, int first_frame, int maxcand, int pf, float *__restrict__ W,
                                                                   int32_t *__restrict__ I) {
-  constexpr int C = 16 * CSTEPS;
+  constexpr int C = 16 * CSTEPS, NV = TK_NV / NCH;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *val = smem;  // [TK_Q][maxcand]
+  float *val = smem;  // [TK_Q][maxcand] (maxcand: candidates of ONE chunk)
   __shared__ float sel_v[TK_Q][MAX_KNN];
   __shared__ int sel_i[TK_Q][MAX_KNN];
   const int q0 = blockIdx.x * TK_Q, nq = min(TK_Q, N - q0), n = blockIdx.y + first_frame;
@@ -142,16 +146,8 @@ __global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float 
   const bool trunc = n > cxt + 1;
   const int nf = trunc ? cxt + 1 : n;
 
-  // A operand: query row q0 + r16 (rows beyond the column repeat the last node: their scores are never stored); lane group g holds
-  // elements 16 j + 4 g .. + 3 of every 16 -- the k order of the MFMA steps, the same for both operands
-  float4 a[CSTEPS];
-  {
-    const float *qp = ehat + ((long)n * N + min(q0 + r16, N - 1)) * C + 4 * g;
-#pragma unroll
-    for (int j = 0; j < CSTEPS; ++j) a[j] = *reinterpret_cast<const float4 *>(qp + 16 * j);
-  }
   const int ulo = max(0, q0 - radius + 1), uhi = min(N - 1, q0 + nq - 1 + radius - 1);
-  const int kt_lo = ulo >> 4, nkt = (uhi >> 4) - kt_lo + 1, nitems = nf * nkt;  // item = (context frame p, key tile kt)
+  const int kt_lo = ulo >> 4, nkt = (uhi >> 4) - kt_lo + 1;  // item = (context frame p, key tile kt)
   int lo_r[4], bw_r[4];  // bands of the four queries whose scores this lane receives (rows 4 g + r of the tile)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -159,91 +155,132 @@ __global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float 
     lo_r[r] = lo;
     bw_r[r] = q < N ? hi - lo + 1 : 0;
   }
-  auto fetch = [&](int item, float4 (&b)[CSTEPS]) {
-    const int p = item / nkt, kt = kt_lo + item - p * nkt;
-    const int frame = trunc ? (p == 0 ? 0 : n - cxt + (p - 1)) : p;
-    const float *kp = ehat + ((long)frame * N + min(16 * kt + r16, N - 1)) * C + 4 * g;
-#pragma unroll
-    for (int j = 0; j < CSTEPS; ++j) b[j] = *reinterpret_cast<const float4 *>(kp + 16 * j);
-  };
-  float4 b[CSTEPS], bn[CSTEPS];
-  if (wave < nitems) fetch(wave, b);
-  for (int item = wave; item < nitems; item += TK_NW) {
-    if (item + TK_NW < nitems) fetch(item + TK_NW, bn);
-    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd steps: two independent chains
-#pragma unroll
-    for (int j = 0; j < CSTEPS; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc1, 0, 0, 0);
-    }
-    const int p = item / nkt, m = 16 * (kt_lo + item - p * nkt) + r16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = m - lo_r[r];
-      if (m < N && rr >= 0 && rr < bw_r[r]) val[(4 * g + r) * maxcand + p * bw_r[r] + rr] = (acc0[r] + acc1[r]) / temp;
-    }
-#pragma unroll
-    for (int j = 0; j < CSTEPS; ++j) b[j] = bn[j];
-  }
-  __syncthreads();
-
   // selection: wave w takes the queries w and w + 8 TOGETHER -- two independent chains of compares / cross-lane exchanges in one
   // instruction stream
-  {
-    const int u0 = wave, u1 = wave + TK_NW;
-    int lo2[2], bw2[2], nc2[2];
+  const int u0 = wave, u1 = wave + TK_NW;
+  int lo2[2], bw2[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = q0 + (h ? u1 : u0), lo = max(0, q - radius + 1), hi = min(N - 1, q + radius - 1);
-      lo2[h] = lo;
-      bw2[h] = hi - lo + 1;
-      nc2[h] = (h ? u1 : u0) < nq ? nf * bw2[h] : 0;
+  for (int h = 0; h < 2; ++h) {
+    const int q = q0 + (h ? u1 : u0), lo = max(0, q - radius + 1), hi = min(N - 1, q + radius - 1);
+    lo2[h] = lo;
+    bw2[h] = hi - lo + 1;
+  }
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int p0 = ch * pf, np = min(nf - p0, NCH == 1 ? nf : pf);  // this chunk's context frames [p0, p0 + np)
+    if (np <= 0) break;                                            // (block-uniform)
+    const int nitems = np * nkt;
+    // A operand: query row q0 + r16 (rows beyond the column repeat the last node: their scores are never stored); lane group g holds
+    // elements 16 j + 4 g .. + 3 of every 16 -- the k order of the MFMA steps, the same for both operands (per chunk: not live
+    // through the selection)
+    float4 a[CSTEPS];
+    {
+      const float *qp = ehat + ((long)n * N + min(q0 + r16, N - 1)) * C + 4 * g;
+#pragma unroll
+      for (int j = 0; j < CSTEPS; ++j) a[j] = *reinterpret_cast<const float4 *>(qp + 16 * j);
     }
-    float v[2][TK_NV];
+    auto fetch = [&](int item, float4 (&b)[CSTEPS]) {
+      const int p = p0 + item / nkt, kt = kt_lo + item % nkt;
+      const int frame = trunc ? (p == 0 ? 0 : n - cxt + (p - 1)) : p;
+      const float *kp = ehat + ((long)frame * N + min(16 * kt + r16, N - 1)) * C + 4 * g;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < TK_NV; ++i) {
-        const int c = lane + 64 * i;
-        v[h][i] = c < nc2[h] ? val[(h ? u1 : u0) * maxcand + c] : -INFINITY;
+      for (int j = 0; j < CSTEPS; ++j) b[j] = *reinterpret_cast<const float4 *>(kp + 16 * j);
+    };
+    // NCH = 1: the next item's key rows are requested before this one's MFMAs (two waves per SIMD); NCH = 2: four waves per SIMD
+    // cover the round trip, and the second register set would not fit 128 registers
+    float4 b[CSTEPS], bn[NCH == 1 ? CSTEPS : 1];
+    if (NCH == 1 && wave < nitems) fetch(wave, b);
+    for (int item = wave; item < nitems; item += TK_NW) {
+      if constexpr (NCH == 1) {
+        if (item + TK_NW < nitems) fetch(item + TK_NW, bn);
+      } else {
+        fetch(item, b);
       }
-    for (int j = 0; j < knn; ++j) {
-      float bv[2];
-      int bi[2];
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd steps: two independent chains
+#pragma unroll
+      for (int j = 0; j < CSTEPS; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc1, 0, 0, 0);
+      }
+      const int pl = item / nkt, m = 16 * (kt_lo + item - pl * nkt) + r16;  // pl: frame slot inside the chunk
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = m - lo_r[r];
+        if (m < N && rr >= 0 && rr < bw_r[r]) val[(4 * g + r) * maxcand + pl * bw_r[r] + rr] = (acc0[r] + acc1[r]) / temp;
+      }
+      if constexpr (NCH == 1) {
+#pragma unroll
+        for (int j = 0; j < CSTEPS; ++j) b[j] = bn[j];
+      }
+    }
+    __syncthreads();
+
+    {
+      int nc2[2], base2[2];
+      float v[2][NV], ve[2];
+      int ie[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        float x = v[h][0];
-        int bs = 0;
+        const int u = h ? u1 : u0;
+        nc2[h] = u < nq ? np * bw2[h] : 0;
+        base2[h] = p0 * bw2[h];  // candidate index of the chunk's first candidate
 #pragma unroll
-        for (int i = 1; i < TK_NV; ++i)
-          if (v[h][i] > x) { x = v[h][i]; bs = i; }  // ties inside a lane: the lowest slot = the lowest candidate index
-        bv[h] = x;
-        bi[h] = x == -INFINITY ? 0x7fffffff : lane + 64 * bs;
+        for (int i = 0; i < NV; ++i) {
+          const int c = lane + 64 * i;
+          v[h][i] = c < nc2[h] ? val[u * maxcand + c] : -INFINITY;
+        }
+        // the k best of the chunks before (lane j holds the j-th): lower candidate indices than anything in this chunk
+        const bool carried = ch > 0 && u < nq && lane < knn;
+        ve[h] = carried ? sel_v[u][lane] : -INFINITY;
+        ie[h] = carried ? sel_i[u][lane] : 0x7fffffff;
+        if (ve[h] == -INFINITY) ie[h] = 0x7fffffff;
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
+      for (int j = 0; j < knn; ++j) {
+        float bv[2];
+        int bi[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float ov = __shfl_xor(bv[h], o);
-          const int oi = __shfl_xor(bi[h], o);
-          if (ov > bv[h] || (ov == bv[h] && oi < bi[h])) { bv[h] = ov; bi[h] = oi; }
+          float x = ve[h];
+          int bs = -1;
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+            if (v[h][i] > x) { x = v[h][i]; bs = i; }  // ties inside a lane: the carried one, then the lowest slot = the lowest index
+          bv[h] = x;
+          bi[h] = x == -INFINITY ? 0x7fffffff : (bs < 0 ? ie[h] : base2[h] + lane + 64 * bs);
         }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (lane == 0 && (h ? u1 : u0) < nq) {
-          sel_v[h ? u1 : u0][j] = bv[h];
-          sel_i[h ? u1 : u0][j] = bi[h];
-        }
-        if (bi[h] != 0x7fffffff && (bi[h] & 63) == lane) {
-          const int slot = bi[h] >> 6;
+        for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-          for (int i = 0; i < TK_NV; ++i)
-            if (i == slot) v[h][i] = -INFINITY;
+          for (int h = 0; h < 2; ++h) {
+            const float ov = __shfl_xor(bv[h], o);
+            const int oi = __shfl_xor(bi[h], o);
+            if (ov > bv[h] || (ov == bv[h] && oi < bi[h])) { bv[h] = ov; bi[h] = oi; }
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (lane == 0 && (h ? u1 : u0) < nq) {
+            sel_v[h ? u1 : u0][j] = bv[h];
+            sel_i[h ? u1 : u0][j] = bi[h];
+          }
+          if (bi[h] != 0x7fffffff) {
+            if (ie[h] == bi[h]) {
+              ve[h] = -INFINITY;
+              ie[h] = 0x7fffffff;
+            } else if (bi[h] >= base2[h] && ((bi[h] - base2[h]) & 63) == lane) {
+              const int slot = (bi[h] - base2[h]) >> 6;
+#pragma unroll
+              for (int i = 0; i < NV; ++i)
+                if (i == slot) v[h][i] = -INFINITY;
+            }
+          }
         }
       }
     }
+    if (NCH > 1) __syncthreads();  // the next chunk's scores overwrite val; lane 0's sel stores are in LDS for the carried reads
+  }
+  {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // lane 0's stores are in LDS before the wave reads them back
 #pragma unroll
@@ -269,22 +306,35 @@ __global__ __launch_bounds__(TK_NT) void labelprop_topk_mfma_kernel(const float 
   }
 }
 
-template <int CSTEPS>
-int launch_topk_mfma(const float *ehat, int T, int N, int cxt, int radius, float temp, int knn, int first_frame, int maxcand, float *W,
-                     int32_t *I, hipStream_t s) {
-  const size_t lds = (size_t)TK_Q * maxcand * 4;
+template <int CSTEPS, int NCH>
+int launch_topk_mfma_n(const float *ehat, int T, int N, int cxt, int radius, float temp, int knn, int first_frame, int chunkcand, int pf,
+                       float *W, int32_t *I, hipStream_t s) {
+  const size_t lds = (size_t)TK_Q * chunkcand * 4;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void *)labelprop_topk_mfma_kernel<CSTEPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+    if (hipFuncSetAttribute((const void *)labelprop_topk_mfma_kernel<CSTEPS, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
         hipSuccess) {
       g_last_hip_error = (int)hipGetLastError();
       return CRW_EHIP;
     }
     attr = true;
   }
-  hipLaunchKernelGGL(labelprop_topk_mfma_kernel<CSTEPS>, dim3((N + TK_Q - 1) / TK_Q, T - first_frame), dim3(TK_NT), lds, s, ehat, T, N, cxt,
-                     radius, temp, knn, first_frame, maxcand, W, I);
+  hipLaunchKernelGGL((labelprop_topk_mfma_kernel<CSTEPS, NCH>), dim3((N + TK_Q - 1) / TK_Q, T - first_frame), dim3(TK_NT), lds, s, ehat, T, N,
+                     cxt, radius, temp, knn, first_frame, chunkcand, pf, W, I);
   return check_launch();
+}
+
+// max_nf context frames of max_bi in-band keys: in one piece, or -- when the scores of a 16-query tile fill more than half a CU's LDS --
+// in two halves, so that two workgroups share a CU (CRW_LABELPROP_TOPK_CHUNKS=1: always one piece, A/B)
+template <int CSTEPS>
+int launch_topk_mfma(const float *ehat, int T, int N, int cxt, int radius, float temp, int knn, int first_frame, int max_nf, int max_bi, float *W,
+                     int32_t *I, hipStream_t s) {
+  static const bool one = getenv("CRW_LABELPROP_TOPK_CHUNKS") && getenv("CRW_LABELPROP_TOPK_CHUNKS")[0] == '1';
+  const long maxcand = (long)max_nf * max_bi;
+  const int pf = (max_nf + 1) / 2;
+  if (!one && CSTEPS <= 8 /* 256 channels: past 128 registers */ && (size_t)TK_Q * maxcand * 4 > 76 * 1024 && (long)pf * max_bi <= 64L * (TK_NV / 2))
+    return launch_topk_mfma_n<CSTEPS, 2>(ehat, T, N, cxt, radius, temp, knn, first_frame, pf * max_bi, pf, W, I, s);
+  return launch_topk_mfma_n<CSTEPS, 1>(ehat, T, N, cxt, radius, temp, knn, first_frame, (int)maxcand, max_nf, W, I, s);
 }
 
 __device__ inline float ld_l2(const float *p) {
@@ -732,9 +782,9 @@ int crw_labelprop_topk_grid(const float *ehat, int T, int N, int C, int cxt_size
   if (grid_w == 1 && !valu && N >= TK_Q && (C == 64 || C == 128 || C == 256) && maxcand <= 64L * TK_NV &&
       (size_t)TK_Q * maxcand * 4 <= 150 * 1024 && (((uintptr_t)ehat) & 15) == 0) {
     hipStream_t s = (hipStream_t)stream;
-    if (C == 64) return launch_topk_mfma<4>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)maxcand, W, I, s);
-    if (C == 128) return launch_topk_mfma<8>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)maxcand, W, I, s);
-    return launch_topk_mfma<16>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)maxcand, W, I, s);
+    if (C == 64) return launch_topk_mfma<4>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)max_nf, (int)max_bi, W, I, s);
+    if (C == 128) return launch_topk_mfma<8>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)max_nf, (int)max_bi, W, I, s);
+    return launch_topk_mfma<16>(ehat, T, N, cxt_size, radius, temp, knn, first_frame, (int)max_nf, (int)max_bi, W, I, s);
   }
   if (lds > 60 * 1024) return CRW_EINVAL;
   hipLaunchKernelGGL(labelprop_topk_kernel, dim3(N, T - first_frame), dim3(256), lds, (hipStream_t)stream, ehat, T,

@@ -36,6 +36,9 @@ VARIANTS = [
     # the stem's forward product at other patch sizes than 16 x 16 on the gathered product of resnet_gemm.hip where the default is the
     # band-per-wave kernel (csrc/resnet_stem.hip rn_stem_fwd_band_kernel)
     ("CRW_RN_STEM_BAND", "0", RESNET, "matches_pytorch_modules or inference_through_propagate or training_step_matches_reference"),
+    # matrix-core top-k with a query tile's scores in one piece (one workgroup per CU at config 5) where the default takes the context
+    # frames in two halves through half the LDS (two workgroups per CU; csrc/labelprop.hip labelprop_topk_mfma_kernel<.., NCH>)
+    ("CRW_LABELPROP_TOPK_CHUNKS", "1", PARITY, "labelprop_topk_on_matrix_cores or labelprop_matches_oracle_mcords_shape or propagate_matches_reference"),
     # label-propagation top-k on the vector kernel where the default scores on the fp32 matrix cores (csrc/labelprop.hip)
     ("CRW_LABELPROP_TOPK_VALU", "1", PARITY, "labelprop_matches_oracle_mcords_shape or labelprop_edge_cases or propagate_matches_reference"),
 ]
